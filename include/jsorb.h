@@ -1,0 +1,135 @@
+/*
+ * jsorb.h - C ABI of libjsorb: the MI355X-native (HIP, gfx950) ORB front-end + stereo matcher that
+ * replaces Jetson-SLAM's CUDA hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Reference interfaces replaced (paths under the reference tree, ashishkumar822/Jetson-SLAM @ 2024-12-18):
+ *   jsorb_create / jsorb_destroy   <- orb_cuda::ORB_GPU::ORB_GPU / ~ORB_GPU   include/cuda/orb_gpu.hpp:26-36, src/cuda/orb_gpu.cpp:22-451
+ *                                     (built by Jetson_SLAM::ORBExtractor::ORBExtractor, include/ORBextractor.h:25-35, src/ORBextractor.cpp:75-87)
+ *   jsorb_extract*                 <- ORBExtractor::extract -> ORB_GPU::extract   include/ORBextractor.h:40-42, src/cuda/orb_gpu.cpp:489-841
+ *   jsorb_keypoints_* / jsorb_descriptors_* <- SyncedMem<int>/<unsigned char>::gpu_data()/to_cpu()  include/cuda/synced_mem_holder.hpp:10-65 (Frame.cpp:119-122)
+ *   jsorb_level_* / jsorb_scale_*  <- public members height_, width_, image_, scale_, inv_scale_  include/cuda/orb_gpu.hpp:240-250 (used by Frame.cpp:784-801)
+ *   jsorb_stereo_match*            <- Frame::ComputeStereoMatches -> ORB_GPU::ORB_compute_stereo_match  src/Frame.cpp:780-803, include/cuda/orb_gpu.hpp:218-229,
+ *                                     src/cuda/orb_stereo_match.cu:105-580
+ *
+ * Output layout is the reference's: keypoints = 6N int32 in six consecutive blocks x[N] y[N] score[N] angle[N] (degrees, f32 bit
+ * pattern) octave[N] size[N]; descriptors = 32N bytes; keypoint order = level-major, tile-raster within a level.
+ * All functions return JSORB_OK (0) or a negative error; nothing throws across this boundary.
+ * Threading: distinct handles may be used concurrently from different host threads (the reference runs the left and right
+ * extractors in two std::threads, Frame.cpp:107-110); one handle is single-threaded.  There is no CPU fallback: if no gfx950
+ * device / code object is available the calls fail with JSORB_ERR_HIP.
+ */
+#ifndef JSORB_H
+#define JSORB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSORB_OK 0
+#define JSORB_ERR_INVALID (-1)      /* bad argument / unsupported parameter combination */
+#define JSORB_ERR_HIP (-2)          /* a HIP runtime call failed (see jsorb_last_error) */
+#define JSORB_ERR_UNSUPPORTED (-3)  /* feature of the reference not built yet (NMS-MS) */
+#define JSORB_ERR_STATE (-4)        /* call order violation (e.g. stereo before extract) */
+
+#define JSORB_MAX_LEVELS 16
+
+typedef struct jsorb_extractor jsorb_extractor;
+
+/* Mirrors the ORB_GPU / ORBExtractor constructor arguments (include/cuda/orb_gpu.hpp:26-36). */
+typedef struct jsorb_params {
+    int height, width;               /* level-0 image size */
+    int n_levels;                    /* ORBextractor.nLevels */
+    float scale_factor;              /* ORBextractor.scaleFactor */
+    int fast_n_min, fast_n_max;      /* ORBextractor.FAST_N_MIN / FAST_N_MAX : bounded arc length */
+    int th_fast_min, th_fast_max;    /* th_FAST_MIN is accepted and ignored exactly as the reference does (orb_gpu.cpp:42-47) */
+    int tile_h, tile_w;              /* ORBextractor.tile_h / tile_w (level 0) */
+    int fixed_multi_scale_tile_size;
+    int apply_nms_ms, nms_ms_mode_gpu;
+    int device_id;                   /* reference hard-wires 0 (ORBextractor.cpp:87) */
+    int max_batch;                   /* images one extract call may process (>=1); 1 = reference behaviour */
+} jsorb_params;
+
+typedef struct jsorb_stereo_stats {
+    int n_left, n_right;
+    int n_candidate_pairs;           /* (iL,iR) pairs whose Hamming distance was evaluated */
+    int n_corr_match;                /* matches refined by the 11x11 L1 window search */
+    int n_depth;                     /* matches with a depth before the median cut */
+    int n_final;                     /* after the 2.1 x median cut */
+} jsorb_stereo_stats;
+
+/* kernel ids for jsorb_kernel_time */
+enum { JSORB_K_PYRAMID = 0, JSORB_K_DETECT, JSORB_K_COMPACT, JSORB_K_BLUR, JSORB_K_DESCRIBE, JSORB_K_STEREO, JSORB_K_MEDIAN, JSORB_K_COUNT };
+
+/* ---- lifetime ---- */
+/* mask: NULL (no mask => all 255) or a height*width u8 level-0 mask in host memory. */
+int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extractor **out);
+void jsorb_destroy(jsorb_extractor *e);
+const char *jsorb_last_error(const jsorb_extractor *e);
+const char *jsorb_version(void);
+
+/* ---- extraction ---- */
+/* Reference-shaped call: one host image (step = bytes per row), results stay on the device; *n_keypoints = N.  Synchronous. */
+int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints);
+/* Same with the image already in device memory. */
+int jsorb_extract_device(jsorb_extractor *e, const uint8_t *dev_image, int step, int *n_keypoints);
+/* Batch mode: n_images (<= max_batch) images at dev_images + i*image_stride, rows `step` bytes apart.  Enqueues only; the
+ * input buffer must stay valid until jsorb_sync (level 0 is read in place).  Results per image via the accessors below. */
+int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images);
+/* Batch mode from pinned/pageable host memory: hipMemcpy2DAsync into the level-0 slab, then the same kernels. */
+int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images);
+/* Wait for everything enqueued on this handle and refresh the host-side counts. */
+int jsorb_sync(jsorb_extractor *e);
+
+/* ---- results (valid after a synchronous call or jsorb_sync, until the next extract on the handle) ---- */
+int jsorb_n_images(const jsorb_extractor *e);
+int jsorb_n_keypoints(const jsorb_extractor *e, int image);
+int jsorb_level_n_keypoints(const jsorb_extractor *e, int image, int level);
+const int32_t *jsorb_keypoints_device(const jsorb_extractor *e, int image);   /* 6N int32, layout above */
+const uint8_t *jsorb_descriptors_device(const jsorb_extractor *e, int image); /* 32N bytes */
+int jsorb_copy_keypoints(const jsorb_extractor *e, int image, int32_t *host_dst /* 6N */);
+int jsorb_copy_descriptors(const jsorb_extractor *e, int image, uint8_t *host_dst /* 32N */);
+
+/* ---- geometry / tables (mirrors ORB_GPU::height_, width_, scale_, inv_scale_, tile grid) ---- */
+int jsorb_n_levels(const jsorb_extractor *e);
+int jsorb_level_dims(const jsorb_extractor *e, int level, int *height, int *width, int *pitch);
+int jsorb_level_tiles(const jsorb_extractor *e, int level, int *tile_h, int *tile_w, int *n_tile_h, int *n_tile_w, int *level_offset);
+int jsorb_total_tiles(const jsorb_extractor *e);
+float jsorb_scale(const jsorb_extractor *e, int level);
+float jsorb_inv_scale(const jsorb_extractor *e, int level);
+/* Device pointer to the un-blurred (blurred=0) or 7x7-blurred (blurred=1) pyramid level of an image (ORB_GPU::image_/image_gaussian_). */
+const uint8_t *jsorb_level_image_device(const jsorb_extractor *e, int image, int level, int blurred);
+int jsorb_copy_level_image(const jsorb_extractor *e, int image, int level, int blurred, uint8_t *host_dst /* H*W, pitch W */);
+/* Per-tile candidates before compaction (x,y,score), T entries each: debugging / stage-level parity. */
+int jsorb_copy_tile_candidates(const jsorb_extractor *e, int image, int32_t *x, int32_t *y, int32_t *score);
+/* Per-keypoint orientation in radians in output order (N floats). */
+int jsorb_copy_angles(const jsorb_extractor *e, int image, float *host_dst);
+
+/* ---- stereo ---- */
+/* Reference-shaped call on image 0 of each handle: fills u_right[N_left], depth[N_left] (host, -1 = no match).  Synchronous.
+ * mb is passed explicitly (the reference reads Frame::mb before it is assigned - SURVEY Appendix C-5); th_high/th_low are
+ * ORBmatcher::TH_HIGH/TH_LOW = 100/50 (ORBmatcher.cpp:24-25). */
+int jsorb_stereo_match(jsorb_extractor *left, jsorb_extractor *right, float mb, float mbf, int th_high, int th_low,
+                       float *u_right, float *depth, jsorb_stereo_stats *stats);
+/* Batch mode: image i of `left` against image i of `right`; enqueues on left's stream after right's work. */
+int jsorb_stereo_match_batch_async(jsorb_extractor *left, jsorb_extractor *right, float mb, float mbf, int th_high, int th_low);
+const float *jsorb_stereo_uright_device(const jsorb_extractor *left, int image);
+const float *jsorb_stereo_depth_device(const jsorb_extractor *left, int image);
+int jsorb_copy_stereo(const jsorb_extractor *left, int image, float *u_right, float *depth, jsorb_stereo_stats *stats);
+
+/* ---- plumbing ---- */
+/* Use an external HIP stream (hipStream_t as void*) instead of the handle's own, e.g. torch's current stream. NULL restores. */
+int jsorb_set_stream(jsorb_extractor *e, void *hip_stream);
+void *jsorb_get_stream(const jsorb_extractor *e);
+/* Per-kernel hipEvent timing (off by default: it serialises launches). Accumulates until reset. */
+int jsorb_enable_kernel_timing(jsorb_extractor *e, int on);
+int jsorb_kernel_time(jsorb_extractor *e, int kernel_id, double *total_ms, long *launches);
+int jsorb_reset_kernel_timing(jsorb_extractor *e);
+const char *jsorb_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JSORB_H */

@@ -1,0 +1,579 @@
+// jsorb_api.hip - host side of libjsorb: the C ABI declared in include/jsorb.h.
+//
+// Mirrors ORB_GPU's host orchestration (src/cuda/orb_gpu.cpp) with an MI355X-first structure:
+//   reference: ~7L+1 launches on L streams + 3 blocking copies + 2 full stream-sync rounds per image,
+//              per-frame cudaMalloc/cudaFree + cublasCreate/Destroy in the stereo matcher
+//   here:      5 launches per BATCH of images (pyramid, detect, compact, blur, describe) + 2 per batch of pairs
+//              (stereo, median) on one stream, no host round trip in the middle, one small D2H of counts at the end,
+//              nothing allocated after jsorb_create.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/jsorb.h"
+#include "jsorb_launch.h"
+
+using namespace jsorb;
+
+namespace {
+
+const char *k_names[JSORB_K_COUNT] = {"k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median"};
+
+struct TimedLaunch { int id; hipEvent_t a, b; };
+
+} // namespace
+
+struct jsorb_extractor {
+    jsorb_params p{};
+    Geometry g{};
+    int B = 1;                 // max_batch
+    int n_images = 0;          // images of the last extract
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t done = nullptr;
+    size_t detect_lds = 0;
+    // device buffers
+    uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
+    uint32_t *lut_bits = nullptr;
+    unsigned long long *tile_out = nullptr, *kp = nullptr;
+    int *counts = nullptr, *row_tab = nullptr;
+    float *angles = nullptr;
+    uint8_t *desc = nullptr;
+    int32_t *out_kp = nullptr;
+    float *st_u = nullptr, *st_d = nullptr;
+    int *st_l1 = nullptr, *st_stats = nullptr;
+    // pinned host mirrors
+    int *h_counts = nullptr, *h_stats = nullptr;
+    ImageSrc src{};            // where level 0 of the last extract lives
+    bool extracted = false, stereo_done = false;
+    int stereo_pairs = 0;
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    double k_ms[JSORB_K_COUNT] = {0};
+    long k_n[JSORB_K_COUNT] = {0};
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(e, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _s = (call);                                                                           \
+        if (_s != hipSuccess) {                                                                           \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_s);                                 \
+            return JSORB_ERR_HIP;                                                                         \
+        }                                                                                                 \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Geometry exactly as ORB_GPU::ORB_GPU computes it (orb_gpu.cpp:49-62, 224-258, 305-327) plus this build's launch tables.
+int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
+{
+    if (p.n_levels < 1 || p.n_levels > JSORB_MAX_LEVELS) { err = "n_levels out of range"; return JSORB_ERR_INVALID; }
+    if (p.height < 1 || p.width < 1 || p.height > 32767 || p.width > 32767) { err = "image size out of range"; return JSORB_ERR_INVALID; }
+    if (p.tile_h < 1 || p.tile_w < 1 || p.tile_w > 128 || p.tile_h > 128) {
+        // the reference launches 128/tile_w tiles per block (orb_FAST_apply_NMS_G.cu:1434): tile_w > 128 divides by zero there
+        err = "tile size must be in [1,128]";
+        return JSORB_ERR_INVALID;
+    }
+    if (!(p.scale_factor > 1.0f) && p.n_levels > 1) { err = "scale_factor must be > 1"; return JSORB_ERR_INVALID; }
+    memset(&g, 0, sizeof(g));
+    g.L = p.n_levels;
+    g.threshold = p.th_fast_max;   // th_FAST_MIN is overwritten in the reference (orb_gpu.cpp:42-47)
+    float scale[JSORB_MAX_LEVELS], inv[JSORB_MAX_LEVELS];
+    scale[0] = 1.0f; inv[0] = 1.0f;
+    g.lv[0].H = p.height; g.lv[0].W = p.width;
+    for (int i = 1; i < g.L; i++) {
+        scale[i] = p.scale_factor * scale[i - 1];
+        inv[i] = 1.0f / scale[i];
+        g.lv[i].H = (int)((float)p.height * inv[i]);
+        g.lv[i].W = (int)((float)p.width * inv[i]);
+        if (g.lv[i].H < 1 || g.lv[i].W < 1) { err = "pyramid level collapses to zero size"; return JSORB_ERR_INVALID; }
+    }
+    int tiles = 0, dblk = 0, bblk = 0, pblk = 0, rtab = 0;
+    unsigned long long off = 0;
+    for (int i = 0; i < g.L; i++) {
+        LevelDesc &lv = g.lv[i];
+        lv.scale = scale[i]; lv.inv_scale = inv[i];
+        lv.pitch = round_up(lv.W, 64);
+        lv.img_off = off;
+        off += (unsigned long long)lv.pitch * lv.H;
+        off = (off + 255) & ~255ull;
+        if (p.fixed_multi_scale_tile_size || i == 0) { lv.th = p.tile_h; lv.tw = p.tile_w; }
+        else { lv.th = (int)((float)p.tile_h * inv[i]); lv.tw = (int)((float)p.tile_w * inv[i]); }
+        if (lv.th < 1 || lv.tw < 1) { err = "tile size collapses to zero at a pyramid level"; return JSORB_ERR_INVALID; }
+        lv.nth = (lv.H - 1) / lv.th + 1;
+        lv.ntw = (lv.W - 1) / lv.tw + 1;
+        lv.tile_off = tiles;
+        tiles += lv.nth * lv.ntw;
+        // K3 launch constants that define the tie-break order (orb_FAST_apply_NMS_G.cu:1405-1434)
+        int n_loc = std::max(1, std::min(10, lv.tw / 3));
+        if (n_loc > lv.th) n_loc = lv.th;
+        int n_ty = (lv.th - 1) / n_loc + 1;
+        if (n_ty * 128 > 1024) n_ty = 1024 / 128;
+        lv.n_ty = n_ty;
+        lv.mini_tile = (lv.th - 1) / n_ty + 1;
+        lv.log2_tw = 0;
+        while ((1 << lv.log2_tw) < lv.tw) lv.log2_tw++;
+        // this build's workgroup tables
+        lv.k_tiles = std::max(1, 126 / lv.tw);
+        lv.groups_per_row = (lv.ntw - 1) / lv.k_tiles + 1;
+        lv.detect_blk0 = dblk;
+        dblk += lv.nth * lv.groups_per_row;
+        lv.row_tab_off = rtab;
+        rtab += lv.nth + 1;
+        const int rw = lv.W - 2 * JSORB_BORDER, rh = lv.H - 2 * JSORB_BORDER;
+        lv.blur_bx = rw > 0 ? (rw + 63) / 64 : 0;
+        lv.blur_by = rh > 0 ? (rh + 31) / 32 : 0;
+        if (lv.blur_bx == 0 || lv.blur_by == 0) { lv.blur_bx = 1; lv.blur_by = 0; }
+        lv.blur_blk0 = bblk;
+        bblk += lv.blur_bx * lv.blur_by;
+        lv.pyr_bx = (lv.W + 255) / 256;
+        lv.pyr_blk0 = pblk;
+        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + 3) / 4);
+    }
+    g.T = tiles;
+    if (tiles >= (1 << 20)) { err = "too many tiles"; return JSORB_ERR_INVALID; }
+    g.detect_blocks = dblk; g.blur_blocks = bblk; g.pyr_blocks = pblk; g.row_tab_len = rtab;
+    g.slab_bytes = off;
+    return JSORB_OK;
+}
+
+// FAST bounded-arc LUT (orb_gpu.cpp:367-436) for all 65536 indices, packed 1 bit per entry.
+void build_lut_bits(int nmin, int nmax, std::vector<uint32_t> &bits)
+{
+    bits.assign(2048, 0u);
+    for (int j = 0; j < 65536; j++) {
+        int run = 0, probe = 0x8000;
+        bool undecided = true;
+        for (int k = 0; k < 16; k++, probe >>= 1) {
+            if (j & probe) { run++; continue; }
+            if (run >= nmin && run <= nmax) { undecided = false; break; }
+            run = 0;
+        }
+        if (undecided) {   // wrap-around: the leading run is appended to the trailing one
+            probe = 0x8000;
+            for (int k = 0; k < 16 && (j & probe); k++, probe >>= 1) run++;
+        }
+        if (run >= nmin && run <= nmax) bits[j >> 5] |= 1u << (j & 31);
+    }
+}
+
+int enqueue_timed(jsorb_extractor *e, int id)
+{
+    if (!e->timing) return JSORB_OK;
+    TimedLaunch t{id, nullptr, nullptr};
+    HIPCHK(e, hipEventCreate(&t.a));
+    HIPCHK(e, hipEventCreate(&t.b));
+    HIPCHK(e, hipEventRecord(t.a, e->stream));
+    e->timed.push_back(t);
+    return JSORB_OK;
+}
+int finish_timed(jsorb_extractor *e)
+{
+    if (!e->timing) return JSORB_OK;
+    HIPCHK(e, hipEventRecord(e->timed.back().b, e->stream));
+    return JSORB_OK;
+}
+int drain_timed(jsorb_extractor *e)
+{
+    for (auto &t : e->timed) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventSynchronize(t.b));
+        HIPCHK(e, hipEventElapsedTime(&ms, t.a, t.b));
+        e->k_ms[t.id] += ms;
+        e->k_n[t.id] += 1;
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    e->timed.clear();
+    return JSORB_OK;
+}
+
+#define TIMED(e, id, stmt)                                   \
+    do {                                                     \
+        int _rc = enqueue_timed((e), (id));                  \
+        if (_rc) return _rc;                                 \
+        stmt;                                                \
+        _rc = finish_timed((e));                             \
+        if (_rc) return _rc;                                 \
+    } while (0)
+
+int run_pipeline(jsorb_extractor *e, int n)
+{
+    const Geometry &g = e->g;
+    TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, n, e->stream));
+    TIMED(e, JSORB_K_DETECT, launch_detect(g, e->src, e->slab, e->mask, e->lut_bits, e->tile_out, n, e->detect_lds, e->stream));
+    TIMED(e, JSORB_K_COMPACT, launch_compact(g, e->tile_out, e->kp, e->counts, e->row_tab, n, e->stream));
+    TIMED(e, JSORB_K_BLUR, launch_blur(g, e->src, e->slab, e->blur, n, e->stream));
+    TIMED(e, JSORB_K_DESCRIBE, launch_describe(g, e->src, e->slab, e->blur, e->kp, e->counts, e->angles, e->desc, e->out_kp, n, e->stream));
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(e->h_counts, e->counts, sizeof(int) * (JSORB_MAX_LEVELS + 1) * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipEventRecord(e->done, e->stream));
+    e->n_images = n;
+    e->extracted = true;
+    e->stereo_done = false;
+    return JSORB_OK;
+}
+
+bool check_image(const jsorb_extractor *e, int image) { return e && e->extracted && image >= 0 && image < e->n_images; }
+
+} // namespace
+
+extern "C" {
+
+const char *jsorb_version(void) { return "jsorb 0.1 (gfx950)"; }
+
+const char *jsorb_kernel_name(int id) { return (id >= 0 && id < JSORB_K_COUNT) ? k_names[id] : ""; }
+
+const char *jsorb_last_error(const jsorb_extractor *e) { return e ? e->err.c_str() : "null handle"; }
+
+int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extractor **out)
+{
+    if (!params || !out) return JSORB_ERR_INVALID;
+    *out = nullptr;
+    jsorb_extractor *e = new (std::nothrow) jsorb_extractor();
+    if (!e) return JSORB_ERR_INVALID;
+    // on any failure the handle is still returned so that jsorb_last_error can be read; the caller destroys it
+    *out = e;
+    e->p = *params;
+    e->B = params->max_batch < 1 ? 1 : params->max_batch;
+    e->device = params->device_id;
+    if (params->apply_nms_ms && params->n_levels > 1) {
+        e->err = "apply_nms_ms (multi-scale NMS / PFA, orb_FAST_apply_NMS_MS.cu) is not built yet";
+        return JSORB_ERR_UNSUPPORTED;
+    }
+    int rc = build_geometry(*params, e->g, e->err);
+    if (rc) return rc;
+    Geometry &g = e->g;
+    g.has_mask = mask ? 1 : 0;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    HIPCHK(e, hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+    e->detect_lds = detect_lds_bytes(g);
+    if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
+    const size_t B = (size_t)e->B, T = (size_t)g.T;
+    const size_t slab_total = B * g.slab_bytes + 4096;
+    HIPCHK(e, hipMalloc(&e->slab, slab_total));
+    HIPCHK(e, hipMalloc(&e->blur, slab_total));
+    HIPCHK(e, hipMemset(e->slab, 0, slab_total));
+    HIPCHK(e, hipMemset(e->blur, 0, slab_total));   // blurred image is 0 outside the ROI (Appendix C-2)
+    HIPCHK(e, hipMalloc(&e->lut_bits, 2048 * sizeof(uint32_t)));
+    HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
+    HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
+    HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
+    HIPCHK(e, hipMalloc(&e->row_tab, B * (size_t)g.row_tab_len * sizeof(int)));
+    HIPCHK(e, hipMalloc(&e->angles, B * T * 4));
+    HIPCHK(e, hipMalloc(&e->desc, B * T * 32));
+    HIPCHK(e, hipMalloc(&e->out_kp, B * T * 6 * 4));
+    HIPCHK(e, hipMalloc(&e->st_u, B * T * 4));
+    HIPCHK(e, hipMalloc(&e->st_d, B * T * 4));
+    HIPCHK(e, hipMalloc(&e->st_l1, B * T * 4));
+    HIPCHK(e, hipMalloc(&e->st_stats, B * 8 * sizeof(int)));
+    HIPCHK(e, hipMemset(e->counts, 0, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
+    HIPCHK(e, hipHostMalloc(&e->h_counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
+    HIPCHK(e, hipHostMalloc(&e->h_stats, B * 8 * sizeof(int)));
+    memset(e->h_counts, 0, B * (JSORB_MAX_LEVELS + 1) * sizeof(int));
+    {
+        std::vector<uint32_t> bits;
+        build_lut_bits(params->fast_n_min, params->fast_n_max, bits);
+        HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (mask) {
+        // orb_gpu.cpp:64-91: nearest-neighbour resample per level, then threshold (>10 -> 255).  OpenCV is not available; the
+        // definition adopted is src = min(floor(dst*src_size/dst_size), src_size-1) - parity with OpenCV's INTER_NN is unpinned.
+        std::vector<uint8_t> m(g.slab_bytes, 0);
+        for (int i = 0; i < g.L; i++) {
+            const LevelDesc &lv = g.lv[i];
+            for (int y = 0; y < lv.H; y++) {
+                int sy = (int)std::floor((double)y * g.lv[0].H / lv.H);
+                if (sy > g.lv[0].H - 1) sy = g.lv[0].H - 1;
+                for (int x = 0; x < lv.W; x++) {
+                    int sx = (int)std::floor((double)x * g.lv[0].W / lv.W);
+                    if (sx > g.lv[0].W - 1) sx = g.lv[0].W - 1;
+                    m[lv.img_off + (size_t)y * lv.pitch + x] = mask[(size_t)sy * g.lv[0].W + sx] > 10 ? 255 : 0;
+                }
+            }
+        }
+        HIPCHK(e, hipMalloc(&e->mask, g.slab_bytes));
+        HIPCHK(e, hipMemcpy(e->mask, m.data(), g.slab_bytes, hipMemcpyHostToDevice));
+    }
+    HIPCHK(e, hipDeviceSynchronize());
+    return JSORB_OK;
+}
+
+void jsorb_destroy(jsorb_extractor *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    void *bufs[] = {e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (e->h_counts) (void)hipHostFree(e->h_counts);
+    if (e->h_stats) (void)hipHostFree(e->h_stats);
+    if (e->done) (void)hipEventDestroy(e->done);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int jsorb_set_stream(jsorb_extractor *e, void *hip_stream)
+{
+    if (!e) return JSORB_ERR_INVALID;
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return JSORB_OK;
+}
+void *jsorb_get_stream(const jsorb_extractor *e) { return e ? (void *)e->stream : nullptr; }
+
+int jsorb_sync(jsorb_extractor *e)
+{
+    if (!e) return JSORB_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return drain_timed(e);
+}
+
+int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
+{
+    if (!e || !host_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    const LevelDesc &l0 = e->g.lv[0];
+    for (int i = 0; i < n_images; i++)   // pinned hipMemcpyAsync path of the north star (one 2-D copy per image)
+        HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
+                                   l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
+    e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
+    return run_pipeline(e, n_images);
+}
+
+int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)
+{
+    if (!e || !dev_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    const LevelDesc &l0 = e->g.lv[0];
+    const bool in_place = (step % 4 == 0) && (((uintptr_t)dev_images) % 4 == 0) && (image_stride % 4 == 0);
+    if (in_place) {   // level 0 is read where it lies: no copy of the grayscale plane
+        e->src.l0 = dev_images; e->src.l0_stride = image_stride; e->src.l0_pitch = step;
+    } else {
+        for (int i = 0; i < n_images; i++)
+            HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, dev_images + (size_t)i * image_stride, step,
+                                       l0.W, l0.H, hipMemcpyDeviceToDevice, e->stream));
+        e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
+    }
+    return run_pipeline(e, n_images);
+}
+
+int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints)
+{
+    int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
+    if (rc) return rc;
+    rc = jsorb_sync(e);
+    if (rc) return rc;
+    if (n_keypoints) *n_keypoints = e->h_counts[JSORB_MAX_LEVELS];
+    return JSORB_OK;
+}
+
+int jsorb_extract_device(jsorb_extractor *e, const uint8_t *dev_image, int step, int *n_keypoints)
+{
+    int rc = jsorb_extract_batch_device_async(e, dev_image, 0, step, 1);
+    if (rc) return rc;
+    rc = jsorb_sync(e);
+    if (rc) return rc;
+    if (n_keypoints) *n_keypoints = e->h_counts[JSORB_MAX_LEVELS];
+    return JSORB_OK;
+}
+
+int jsorb_n_images(const jsorb_extractor *e) { return e ? e->n_images : 0; }
+int jsorb_n_keypoints(const jsorb_extractor *e, int image)
+{
+    return check_image(e, image) ? e->h_counts[image * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] : JSORB_ERR_STATE;
+}
+int jsorb_level_n_keypoints(const jsorb_extractor *e, int image, int level)
+{
+    if (!check_image(e, image) || level < 0 || level >= e->g.L) return JSORB_ERR_STATE;
+    return e->h_counts[image * (JSORB_MAX_LEVELS + 1) + level];
+}
+const int32_t *jsorb_keypoints_device(const jsorb_extractor *e, int image)
+{
+    return check_image(e, image) ? e->out_kp + (size_t)image * 6 * e->g.T : nullptr;
+}
+const uint8_t *jsorb_descriptors_device(const jsorb_extractor *e, int image)
+{
+    return check_image(e, image) ? e->desc + (size_t)image * 32 * e->g.T : nullptr;
+}
+int jsorb_copy_keypoints(const jsorb_extractor *e, int image, int32_t *dst)
+{
+    if (!check_image(e, image) || !dst) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(e, image);
+    if (n <= 0) return JSORB_OK;
+    return hipMemcpy(dst, jsorb_keypoints_device(e, image), (size_t)n * 6 * 4, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
+int jsorb_copy_descriptors(const jsorb_extractor *e, int image, uint8_t *dst)
+{
+    if (!check_image(e, image) || !dst) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(e, image);
+    if (n <= 0) return JSORB_OK;
+    return hipMemcpy(dst, jsorb_descriptors_device(e, image), (size_t)n * 32, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
+
+int jsorb_n_levels(const jsorb_extractor *e) { return e ? e->g.L : 0; }
+int jsorb_total_tiles(const jsorb_extractor *e) { return e ? e->g.T : 0; }
+int jsorb_level_dims(const jsorb_extractor *e, int level, int *h, int *w, int *pitch)
+{
+    if (!e || level < 0 || level >= e->g.L) return JSORB_ERR_INVALID;
+    if (h) *h = e->g.lv[level].H;
+    if (w) *w = e->g.lv[level].W;
+    if (pitch) *pitch = (level == 0 && e->extracted) ? e->src.l0_pitch : e->g.lv[level].pitch;
+    return JSORB_OK;
+}
+int jsorb_level_tiles(const jsorb_extractor *e, int level, int *th, int *tw, int *nth, int *ntw, int *off)
+{
+    if (!e || level < 0 || level >= e->g.L) return JSORB_ERR_INVALID;
+    const LevelDesc &lv = e->g.lv[level];
+    if (th) *th = lv.th;
+    if (tw) *tw = lv.tw;
+    if (nth) *nth = lv.nth;
+    if (ntw) *ntw = lv.ntw;
+    if (off) *off = lv.tile_off;
+    return JSORB_OK;
+}
+float jsorb_scale(const jsorb_extractor *e, int level) { return (e && level >= 0 && level < e->g.L) ? e->g.lv[level].scale : 0.f; }
+float jsorb_inv_scale(const jsorb_extractor *e, int level) { return (e && level >= 0 && level < e->g.L) ? e->g.lv[level].inv_scale : 0.f; }
+
+const uint8_t *jsorb_level_image_device(const jsorb_extractor *e, int image, int level, int blurred)
+{
+    if (!check_image(e, image) || level < 0 || level >= e->g.L) return nullptr;
+    if (blurred) return e->blur + (size_t)image * e->g.slab_bytes + e->g.lv[level].img_off;
+    if (level == 0) return e->src.l0 + (size_t)image * e->src.l0_stride;
+    return e->slab + (size_t)image * e->g.slab_bytes + e->g.lv[level].img_off;
+}
+int jsorb_copy_level_image(const jsorb_extractor *e, int image, int level, int blurred, uint8_t *dst)
+{
+    const uint8_t *p = jsorb_level_image_device(e, image, level, blurred);
+    if (!p || !dst) return JSORB_ERR_STATE;
+    const LevelDesc &lv = e->g.lv[level];
+    const int pitch = (!blurred && level == 0) ? e->src.l0_pitch : lv.pitch;
+    return hipMemcpy2D(dst, lv.W, p, pitch, lv.W, lv.H, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
+int jsorb_copy_tile_candidates(const jsorb_extractor *e, int image, int32_t *x, int32_t *y, int32_t *score)
+{
+    if (!check_image(e, image)) return JSORB_ERR_STATE;
+    std::vector<unsigned long long> t(e->g.T);
+    if (hipMemcpy(t.data(), e->tile_out + (size_t)image * e->g.T, (size_t)e->g.T * 8, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
+    for (int i = 0; i < e->g.T; i++) {
+        if (x) x[i] = (int32_t)(t[i] & 0xFFFF);
+        if (y) y[i] = (int32_t)((t[i] >> 16) & 0xFFFF);
+        if (score) score[i] = (int32_t)((t[i] >> 32) & 0xFFF);
+    }
+    return JSORB_OK;
+}
+int jsorb_copy_angles(const jsorb_extractor *e, int image, float *dst)
+{
+    if (!check_image(e, image) || !dst) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(e, image);
+    if (n <= 0) return JSORB_OK;
+    return hipMemcpy(dst, e->angles + (size_t)image * e->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
+
+int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float mb, float mbf, int th_high, int th_low)
+{
+    if (!l || !r) return JSORB_ERR_INVALID;
+    if (!l->extracted || !r->extracted || l->n_images != r->n_images) { l->err = "stereo_match needs one extract on each handle with equal image counts"; return JSORB_ERR_STATE; }
+    if (l->g.T != r->g.T || l->g.L != r->g.L || l->g.lv[0].H != r->g.lv[0].H || l->g.lv[0].W != r->g.lv[0].W || l->device != r->device) {
+        l->err = "left/right extractors differ in geometry";
+        return JSORB_ERR_INVALID;
+    }
+    HIPCHK(l, hipSetDevice(l->device));
+    const int n = l->n_images;
+    if (r->stream != l->stream) HIPCHK(l, hipStreamWaitEvent(l->stream, r->done, 0));
+    StereoArgs sa;
+    sa.maxD = mbf / mb;                  // const float maxD = mbf/minZ  (orb_stereo_match.cu:144-146)
+    sa.mbf = mbf;
+    sa.th_high = th_high;
+    sa.th_orb = (th_high + th_low) / 2;
+    HIPCHK(l, hipMemsetAsync(l->st_stats, 0, sizeof(int) * 8 * n, l->stream));
+    TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts,
+                                          r->desc, r->row_tab, l->st_u, l->st_d, l->st_l1, l->st_stats, sa, n, l->stream));
+    TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts, l->st_u, l->st_d, l->st_l1, l->st_stats, n, l->stream));
+    HIPCHK(l, hipGetLastError());
+    HIPCHK(l, hipMemcpyAsync(l->h_stats, l->st_stats, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, l->stream));
+    HIPCHK(l, hipEventRecord(l->done, l->stream));
+    l->stereo_done = true;
+    l->stereo_pairs = n;
+    return JSORB_OK;
+}
+
+const float *jsorb_stereo_uright_device(const jsorb_extractor *l, int image)
+{
+    return (check_image(l, image) && l->stereo_done) ? l->st_u + (size_t)image * l->g.T : nullptr;
+}
+const float *jsorb_stereo_depth_device(const jsorb_extractor *l, int image)
+{
+    return (check_image(l, image) && l->stereo_done) ? l->st_d + (size_t)image * l->g.T : nullptr;
+}
+
+int jsorb_copy_stereo(const jsorb_extractor *l, int image, float *u_right, float *depth, jsorb_stereo_stats *stats)
+{
+    if (!check_image(l, image) || !l->stereo_done) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(l, image);
+    if (n > 0 && u_right && hipMemcpy(u_right, l->st_u + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
+    if (n > 0 && depth && hipMemcpy(depth, l->st_d + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
+    if (stats) {
+        const int *s = l->h_stats + image * 8;
+        stats->n_left = n;
+        stats->n_right = -1;
+        stats->n_candidate_pairs = s[0];
+        stats->n_corr_match = s[1];
+        stats->n_depth = s[2];
+        stats->n_final = s[3];
+    }
+    return JSORB_OK;
+}
+
+int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float mbf, int th_high, int th_low, float *u_right,
+                       float *depth, jsorb_stereo_stats *stats)
+{
+    int rc = jsorb_stereo_match_batch_async(l, r, mb, mbf, th_high, th_low);
+    if (rc) return rc;
+    rc = jsorb_sync(l);
+    if (rc) return rc;
+    rc = jsorb_copy_stereo(l, 0, u_right, depth, stats);
+    if (rc) return rc;
+    if (stats) stats->n_right = jsorb_n_keypoints(r, 0);
+    return JSORB_OK;
+}
+
+int jsorb_enable_kernel_timing(jsorb_extractor *e, int on)
+{
+    if (!e) return JSORB_ERR_INVALID;
+    e->timing = on != 0;
+    return JSORB_OK;
+}
+int jsorb_kernel_time(jsorb_extractor *e, int id, double *total_ms, long *launches)
+{
+    if (!e || id < 0 || id >= JSORB_K_COUNT) return JSORB_ERR_INVALID;
+    int rc = drain_timed(e);
+    if (rc) return rc;
+    if (total_ms) *total_ms = e->k_ms[id];
+    if (launches) *launches = e->k_n[id];
+    return JSORB_OK;
+}
+int jsorb_reset_kernel_timing(jsorb_extractor *e)
+{
+    if (!e) return JSORB_ERR_INVALID;
+    int rc = drain_timed(e);
+    for (int i = 0; i < JSORB_K_COUNT; i++) { e->k_ms[i] = 0; e->k_n[i] = 0; }
+    return rc;
+}
+
+} // extern "C"

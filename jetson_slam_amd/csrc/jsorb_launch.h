@@ -1,0 +1,37 @@
+// jsorb_launch.h - host-callable launchers of the gfx950 kernels (one translation unit per stage).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jsorb_device.h"
+
+namespace jsorb {
+
+struct StereoArgs {
+    float maxD;        // mbf / mb                 (orb_stereo_match.cu:146)
+    float mbf;
+    int th_high;       // ORBmatcher::TH_HIGH
+    int th_orb;        // (TH_HIGH + TH_LOW) / 2    (orb_stereo_match.cu:226)
+};
+
+// dynamic LDS bytes the detect kernel needs for the given geometry (max over levels)
+size_t detect_lds_bytes(const Geometry &g);
+
+void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, int n_images, hipStream_t s);
+void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
+                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);
+void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
+                    int *row_tab, int n_images, hipStream_t s);
+void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s);
+void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *blur_slab,
+                     const unsigned long long *kp, const int *counts, float *angles, uint8_t *desc, int32_t *out_kp,
+                     int n_images, hipStream_t s);
+void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
+                   const int32_t *outL, const int *countsL, const uint8_t *descL,
+                   const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
+                   float *u_right, float *depth, int *best_l1, int *stats, StereoArgs a, int n_pairs, hipStream_t s);
+void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, int *stats,
+                   int n_pairs, hipStream_t s);
+
+} // namespace jsorb

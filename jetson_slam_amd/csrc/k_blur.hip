@@ -1,0 +1,104 @@
+// k_blur.hip - 7x7 sigma=10 "Gaussian" of every pyramid level of every image of a batch in ONE launch.
+//
+// Semantics: reference K9 imgaussian_GPU (src/cuda/orb_gaussian.cu:21-138): for each pixel of the interior ROI
+// [20,H-20) x [20,W-20): acc = 0; 49 chained single-rounding FMAs acc = fma(w[k], (float)I, acc) in raster order;
+// out = trunc(acc).  Pixels outside the ROI are never written and read as 0 (the blurred
+// slab is zero-filled once at create).  The weights are the hard-coded table of Appendix A.2.
+// MI355X design: a 256-thread workgroup stages a (32+6) x (64+12) byte tile in LDS with aligned dword loads; each
+// thread produces an 8-pixel strip, reading every tile row as two ds_read_b64 and converting each byte once per
+// row (14 v_cvt_f32_ubyte instead of 56); the 8 independent FMA chains interleave freely while each chain keeps
+// the reference order.
+#include "jsorb_launch.h"
+
+namespace jsorb {
+
+// normalised weight by squared distance d = j*j + k*k from the centre (Appendix A.2)
+__device__ __forceinline__ constexpr unsigned gauss_bits(int d)
+{
+    return d == 0 ? 0x3CADF459u : d == 1 ? 0x3CAD163Eu : d == 2 ? 0x3CAC393Fu : d == 4 ? 0x3CAA828Du :
+           d == 5 ? 0x3CA9A8D7u : d == 8 ? 0x3CA72236u : d == 9 ? 0x3CA64CD0u : d == 10 ? 0x3CA5787Bu :
+           d == 13 ? 0x3CA301D1u : 0x3C9EFB81u /* d == 18 */;
+}
+
+#define BLUR_TW 64
+#define BLUR_TH 32
+#define BLUR_STRIDE 80
+
+__global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab)
+{
+    __shared__ __align__(16) unsigned char tile[(BLUR_TH + 6) * BLUR_STRIDE];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int blk = blockIdx.x;
+    int lvl = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.L; i++)
+        if (blk >= g.lv[i].blur_blk0) lvl = i;
+    const LevelDesc &lv = g.lv[lvl];
+    const int lb = blk - lv.blur_blk0;
+    const int bx = lb % lv.blur_bx, by = lb / lv.blur_bx;
+    const int H = lv.H, W = lv.W;
+    const int x0 = JSORB_BORDER + bx * BLUR_TW, y0 = JSORB_BORDER + by * BLUR_TH;
+    int pitch;
+    const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
+
+    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_STRIDE / 4); i += 256) {
+        const int ly = i / (BLUR_STRIDE / 4), dx = i - ly * (BLUR_STRIDE / 4);
+        const int y = y0 - 3 + ly, x = x0 - 4 + 4 * dx;
+        unsigned v = 0;
+        if (y < H && x + 4 <= pitch) v = *reinterpret_cast<const unsigned *>(img + (size_t)y * pitch + x);
+        reinterpret_cast<unsigned *>(tile)[i] = v;
+    }
+    __syncthreads();
+
+    const int ty = tid >> 3, tx = tid & 7;
+    const int y = y0 + ty, x = x0 + 8 * tx;
+    if (y >= H - JSORB_BORDER || x >= W - JSORB_BORDER) return;
+
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint2 *p = reinterpret_cast<const uint2 *>(tile + (ty + r) * BLUR_STRIDE + 8 * tx);
+        const uint2 lo = p[0], hi = p[1];
+        float f[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f[k] = (float)((lo.x >> (8 * k)) & 0xFFu);
+            f[4 + k] = (float)((lo.y >> (8 * k)) & 0xFFu);
+            f[8 + k] = (float)((hi.x >> (8 * k)) & 0xFFu);
+            f[12 + k] = (float)((hi.y >> (8 * k)) & 0xFFu);
+        }
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            const float w = __uint_as_float(gauss_bits((r - 3) * (r - 3) + (c - 3) * (c - 3)));
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(w, f[1 + j + c], acc[j]);
+        }
+    }
+    unsigned o0 = 0, o1 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        o0 |= ((unsigned)acc[j] & 0xFFu) << (8 * j);
+        o1 |= ((unsigned)acc[4 + j] & 0xFFu) << (8 * j);
+    }
+    uint8_t *dst = blur_slab + (size_t)b * g.slab_bytes + lv.img_off + (size_t)y * lv.pitch + x;
+    const int n_valid = (W - JSORB_BORDER) - x;      // pixels of the strip inside the ROI
+    if (n_valid >= 8) {
+        reinterpret_cast<unsigned *>(dst)[0] = o0;
+        reinterpret_cast<unsigned *>(dst)[1] = o1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < n_valid) dst[j] = (uint8_t)(((j < 4 ? o0 : o1) >> (8 * (j & 3))) & 0xFFu);
+    }
+}
+
+void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s)
+{
+    if (g.blur_blocks == 0) return;
+    hipLaunchKernelGGL(k_blur, dim3(g.blur_blocks, n_images), dim3(256), 0, s, g, src, slab, blur_slab);
+}
+
+} // namespace jsorb

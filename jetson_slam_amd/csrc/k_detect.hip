@@ -1,0 +1,241 @@
+// k_detect.hip - fused FAST score + 3x3 NMS + per-tile arg-max ("feature culling"), all levels and all images
+// of a batch in ONE launch.  The int32 score plane of the reference never exists in HBM: a workgroup stages an
+// image tile (+4 px halo) in LDS, keeps the scores of its tile group (+1 px NMS halo) in LDS as u16 and emits
+// one packed (x, y, score) candidate per tile.
+//
+// Semantics restated (bit-exact):
+//   K2 FASTComputeScoreGPU_patternSize_16_lookup_mask  src/cuda/orb_FAST_compute_score.cu:1412-1560
+//      mask test, two early rejects (ring px 4/12, then 0/8), 16-bit brighter/darker masks, bounded-arc LUT,
+//      score = sum |p_k - v| ; written only for the interior [20,H-20) x [20,W-20) ; 0 elsewhere.
+//   K3 Tile_unrolling_reduction_kernel_v2              src/cuda/orb_FAST_apply_NMS_G.cu:1178-1384
+//      score kept iff >= its 8 neighbours; per tile the maximum wins; ties are resolved by the reference's thread
+//      layout: within a column by (ty, k) = ((y - r*th) % n_ty, (y - r*th) / n_ty) lexicographic, across columns
+//      by the ceil-halving tree over shared memory including its stale-slot re-reads.
+// MI355X design:
+//   * phase 1 (all pixels): the two early rejects, 5 LDS byte reads per pixel.  Survivors (typically < 15 %) are
+//     compacted into an LDS work list with wave64 __ballot + popcount prefix, so phase 2 runs on dense waves.
+//   * phase 2 (survivors): 16-pixel ring, LUT bit test (8 KB bit table, L1/L2 resident), SAD score -> LDS.
+//   * phase 3 (survivors with score > 0): 3x3 NMS from LDS and one ds_max_u32 per column with the key
+//     (score << 16 | 0xFFFF - rank), rank = ty * mini_tile + k : the max key IS the reference's column winner.
+//   * phase 4: the reference's horizontal tree replayed literally on <= 128 column slots in LDS.
+#include "jsorb_launch.h"
+
+namespace jsorb {
+
+struct DetectLds {
+    int img_stride;      // bytes per LDS image row
+    int img_rows;        // th + 8
+    int score_w;         // k*tw + 2
+    int score_rows;      // th + 2
+    size_t off_score, off_list, off_colkey, off_tree, off_count, total;
+};
+
+__host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_tiles)
+{
+    DetectLds d;
+    const int ktw = k_tiles * tw;
+    d.img_stride = ((ktw + 8 + 3 + 3) & ~3) + 4;   // window is dword aligned on the left: up to 3 extra bytes
+    d.img_rows = th + 8;
+    d.score_w = ktw + 2;
+    d.score_rows = th + 2;
+    size_t o = (size_t)d.img_stride * d.img_rows;
+    o = (o + 15) & ~(size_t)15;
+    d.off_score = o;
+    o += (size_t)d.score_w * d.score_rows * 2;
+    o = (o + 15) & ~(size_t)15;
+    d.off_list = o;
+    o += (size_t)d.score_w * d.score_rows * 2;
+    o = (o + 15) & ~(size_t)15;
+    d.off_colkey = o;
+    o += 128 * 4;
+    d.off_tree = o;
+    o += 128 * 8;
+    d.off_count = o;
+    o += 16;
+    d.total = o;
+    return d;
+}
+
+size_t detect_lds_bytes(const Geometry &g)
+{
+    size_t m = 0;
+    for (int i = 0; i < g.L; i++) {
+        DetectLds d = detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles);
+        if (d.total > m) m = d.total;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
+                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int blk = blockIdx.x;
+    int lvl = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.L; i++)
+        if (blk >= g.lv[i].detect_blk0) lvl = i;
+    const LevelDesc &lv = g.lv[lvl];
+    const int H = lv.H, W = lv.W, th = lv.th, tw = lv.tw;
+    const int lb = blk - lv.detect_blk0;
+    const int r = lb / lv.groups_per_row, grp = lb % lv.groups_per_row;
+    const int ktw = lv.k_tiles * tw;
+    const int xg0 = grp * ktw;            // first image column of the tile group
+    const int y0 = r * th;                // first image row of the tile row
+    const DetectLds L = detect_lds_layout(th, tw, lv.k_tiles);
+    unsigned char *s_img = smem;
+    unsigned short *s_score = reinterpret_cast<unsigned short *>(smem + L.off_score);
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
+    unsigned *s_colkey = reinterpret_cast<unsigned *>(smem + L.off_colkey);
+    unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
+    int *s_count = reinterpret_cast<int *>(smem + L.off_count);
+
+    int pitch;
+    const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
+
+    // ---- phase 0: stage image rows [y0-4, y0+th+4) x cols [xs, xs+4*nd) ; zero the score tile ----
+    const int xs = (xg0 - 4) & ~3;                        // dword aligned (may be negative)
+    const int nd = L.img_stride >> 2;
+    for (int i = tid; i < L.img_rows * nd; i += 256) {
+        const int ly = i / nd, dx = i - ly * nd;
+        const int y = y0 - 4 + ly, x = xs + 4 * dx;
+        unsigned v = 0;
+        if (y >= 0 && y < H && x >= 0 && x + 4 <= pitch) v = *reinterpret_cast<const unsigned *>(img + (size_t)y * pitch + x);
+        reinterpret_cast<unsigned *>(s_img)[ly * nd + dx] = v;
+    }
+    {
+        const int nsc = (L.score_w * L.score_rows + 1) >> 1;
+        unsigned *z = reinterpret_cast<unsigned *>(s_score);
+        for (int i = tid; i < nsc; i += 256) z[i] = 0;
+        if (tid < 128) s_colkey[tid] = 0;
+        if (tid == 0) *s_count = 0;
+    }
+    __syncthreads();
+
+    // ---- phase 1: early rejects on every pixel of the (th+2) x (ktw+2) score region ----
+    const int threshold = g.threshold;
+    const int lx_off = (xg0 - 1) - xs;                    // LDS column of region column 0
+    const uint8_t *mask = g.has_mask ? mask_slab + lv.img_off : nullptr;
+    for (int ry = wave; ry < L.score_rows; ry += 4) {
+        const int y = y0 - 1 + ry;
+        if (y < JSORB_BORDER || y >= H - JSORB_BORDER) continue;     // wave-uniform
+        const unsigned char *row = s_img + (ry + 3) * L.img_stride + lx_off;
+        for (int rx0 = 0; rx0 < L.score_w; rx0 += 64) {
+            const int rx = rx0 + lane;
+            const int x = xg0 - 1 + rx;
+            bool pass = false;
+            if (rx < L.score_w && x >= JSORB_BORDER && x < W - JSORB_BORDER) {
+                bool m = true;
+                if (mask) m = mask[(size_t)y * lv.pitch + x] != 0;
+                if (m) {
+                    const int v = row[rx], vt = v + threshold, v_t = v - threshold;
+                    const int p4 = row[rx + 3], p12 = row[rx - 3];
+                    if (!(p4 <= vt && p4 >= v_t && p12 <= vt && p12 >= v_t)) {
+                        const int p0 = row[rx + 3 * L.img_stride], p8 = row[rx - 3 * L.img_stride];
+                        pass = !(p0 <= vt && p0 >= v_t && p8 <= vt && p8 >= v_t);
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (bal) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(s_count, __popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (pass) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((ry << 8) | rx);
+            }
+        }
+    }
+    __syncthreads();
+    const int n_surv = *s_count;
+
+    // ---- phase 2: full 16-ring test + score for the survivors ----
+    const int S = L.img_stride;
+    for (int i = tid; i < n_surv; i += 256) {
+        const int e = s_list[i], ry = e >> 8, rx = e & 255;
+        const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
+        const int v = c[0], vt = v + threshold, v_t = v - threshold;
+        int p[16];
+        p[0] = c[3 * S];       p[1] = c[3 * S + 1];   p[2] = c[2 * S + 2];   p[3] = c[S + 3];
+        p[4] = c[3];           p[5] = c[-S + 3];      p[6] = c[-2 * S + 2];  p[7] = c[-3 * S + 1];
+        p[8] = c[-3 * S];      p[9] = c[-3 * S - 1];  p[10] = c[-2 * S - 2]; p[11] = c[-S - 3];
+        p[12] = c[-3];         p[13] = c[S - 3];      p[14] = c[2 * S - 2];  p[15] = c[3 * S - 1];
+        unsigned bright = 0, dark = 0;
+        int sad = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            bright |= (unsigned)(p[k] > vt) << k;
+            dark |= (unsigned)(p[k] < v_t) << k;
+            const int d = p[k] - v;
+            sad += d < 0 ? -d : d;
+        }
+        const unsigned hit = ((lut_bits[bright >> 5] >> (bright & 31)) | (lut_bits[dark >> 5] >> (dark & 31))) & 1u;
+        if (hit) s_score[ry * L.score_w + rx] = (unsigned short)sad;
+    }
+    __syncthreads();
+
+    // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key ----
+    const int SW = L.score_w;
+    for (int i = tid; i < n_surv; i += 256) {
+        const int e = s_list[i], ry = e >> 8, rx = e & 255;
+        if (ry < 1 || ry > th || rx < 1 || rx > ktw) continue;        // halo entries only serve as neighbours
+        const unsigned short *q = s_score + ry * SW + rx;
+        const int s = q[0];
+        if (s == 0) continue;
+        const bool valid = s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
+                           s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];
+        if (!valid) continue;
+        const int dy = ry - 1;
+        const int kk = dy / lv.n_ty, ty = dy - kk * lv.n_ty;
+        const unsigned rank = (unsigned)(ty * lv.mini_tile + kk);
+        atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
+    }
+    __syncthreads();
+
+    // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
+    const bool active = tid < ktw && (xg0 + tid) < W;
+    int tile_in_grp = 0, tile_loc = 0;
+    unsigned long long cur = 0;
+    if (tid < 128) {
+        tile_in_grp = tid / tw;
+        tile_loc = tid - tile_in_grp * tw;
+        int sc = 0, yy = y0;
+        if (tid < ktw) {
+            const unsigned key = s_colkey[tid];
+            sc = (int)(key >> 16);
+            if (sc > 0) {
+                const int rank = (int)(0xFFFFu - (key & 0xFFFFu));
+                const int ty = rank / lv.mini_tile, kk = rank - ty * lv.mini_tile;
+                yy = y0 + ty + kk * lv.n_ty;
+            }
+        }
+        cur = pack_kp(sc, 0, yy, xg0 + tid);
+        s_tree[tid] = cur;
+    }
+    __syncthreads();
+    int gs = (tw - 1) / 2 + 1;
+    for (int it = 0; it < lv.log2_tw; it++) {
+        if (active && tile_loc < gs) {
+            if (tile_loc + gs < tw) {
+                const unsigned long long t = s_tree[tid + gs];
+                if (kp_score(cur) < kp_score(t)) cur = t;
+            }
+            s_tree[tid] = cur;
+        }
+        gs = (gs - 1) / 2 + 1;
+        __syncthreads();
+    }
+    if (active && tile_loc == 0) {
+        const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tile_in_grp;
+        tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] = cur;
+    }
+}
+
+void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
+                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_detect, dim3(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out);
+}
+
+} // namespace jsorb
