@@ -118,11 +118,16 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *left, jsorb_extractor *right
 const float *jsorb_stereo_uright_device(const jsorb_extractor *left, int image);
 const float *jsorb_stereo_depth_device(const jsorb_extractor *left, int image);
 int jsorb_copy_stereo(const jsorb_extractor *left, int image, float *u_right, float *depth, jsorb_stereo_stats *stats);
+/* Multi-GPU batch mode: write (N_left, N_right, N_matched) of every pair of the last batch, 3 int32 per pair, to a DEVICE
+ * buffer (enqueued on left's stream) - the payload of the one collective of this path, an all-gather of per-pair counts. */
+int jsorb_gather_counts_async(jsorb_extractor *left, jsorb_extractor *right, int32_t *dev_dst);
 
 /* ---- plumbing ---- */
 /* Use an external HIP stream (hipStream_t as void*) instead of the handle's own, e.g. torch's current stream. NULL restores. */
 int jsorb_set_stream(jsorb_extractor *e, void *hip_stream);
 void *jsorb_get_stream(const jsorb_extractor *e);
+/* Make another HIP stream (e.g. the one a collective will be issued on) wait for everything enqueued so far on this handle. */
+int jsorb_stream_wait_done(jsorb_extractor *e, void *other_hip_stream);
 /* Per-kernel hipEvent timing (off by default: it serialises launches). Accumulates until reset. */
 int jsorb_enable_kernel_timing(jsorb_extractor *e, int on);
 int jsorb_kernel_time(jsorb_extractor *e, int kernel_id, double *total_ms, long *launches);

@@ -37,7 +37,9 @@ struct jsorb_extractor {
     int n_images = 0;          // images of the last extract
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;         // recorded after the last enqueued work of this handle
+    hipEvent_t readers_done = nullptr; // recorded on ANOTHER handle's stream after it finished reading this handle's buffers
+    bool has_readers = false;
     size_t detect_lds = 0;
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
@@ -210,6 +212,10 @@ int drain_timed(jsorb_extractor *e)
 int run_pipeline(jsorb_extractor *e, int n)
 {
     const Geometry &g = e->g;
+    if (e->has_readers) {   // a stereo match enqueued on the other handle's stream may still read our previous results
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->readers_done, 0));
+        e->has_readers = false;
+    }
     TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, n, e->stream));
     TIMED(e, JSORB_K_DETECT, launch_detect(g, e->src, e->slab, e->mask, e->lut_bits, e->tile_out, n, e->detect_lds, e->stream));
     TIMED(e, JSORB_K_COMPACT, launch_compact(g, e->tile_out, e->kp, e->counts, e->row_tab, n, e->stream));
@@ -259,6 +265,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     HIPCHK(e, hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->readers_done, hipEventDisableTiming));
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
     const size_t B = (size_t)e->B, T = (size_t)g.T;
@@ -324,6 +331,7 @@ void jsorb_destroy(jsorb_extractor *e)
     if (e->h_counts) (void)hipHostFree(e->h_counts);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->done) (void)hipEventDestroy(e->done);
+    if (e->readers_done) (void)hipEventDestroy(e->readers_done);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -335,6 +343,14 @@ int jsorb_set_stream(jsorb_extractor *e, void *hip_stream)
     return JSORB_OK;
 }
 void *jsorb_get_stream(const jsorb_extractor *e) { return e ? (void *)e->stream : nullptr; }
+
+int jsorb_stream_wait_done(jsorb_extractor *e, void *other)
+{
+    if (!e) return JSORB_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    if ((hipStream_t)other != e->stream) HIPCHK(e, hipStreamWaitEvent((hipStream_t)other, e->done, 0));
+    return JSORB_OK;
+}
 
 int jsorb_sync(jsorb_extractor *e)
 {
@@ -508,6 +524,10 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     HIPCHK(l, hipGetLastError());
     HIPCHK(l, hipMemcpyAsync(l->h_stats, l->st_stats, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, l->stream));
     HIPCHK(l, hipEventRecord(l->done, l->stream));
+    if (r != l && r->stream != l->stream) {
+        HIPCHK(l, hipEventRecord(r->readers_done, l->stream));
+        r->has_readers = true;
+    }
     l->stereo_done = true;
     l->stereo_pairs = n;
     return JSORB_OK;
@@ -537,6 +557,17 @@ int jsorb_copy_stereo(const jsorb_extractor *l, int image, float *u_right, float
         stats->n_depth = s[2];
         stats->n_final = s[3];
     }
+    return JSORB_OK;
+}
+
+int jsorb_gather_counts_async(jsorb_extractor *l, jsorb_extractor *r, int32_t *dev_dst)
+{
+    if (!l || !r || !dev_dst) return JSORB_ERR_INVALID;
+    if (!l->stereo_done || l->n_images != r->n_images) { l->err = "gather_counts needs a finished stereo batch"; return JSORB_ERR_STATE; }
+    HIPCHK(l, hipSetDevice(l->device));
+    launch_gather_counts(l->counts, r->counts, l->st_stats, dev_dst, l->n_images, l->stream);
+    HIPCHK(l, hipGetLastError());
+    HIPCHK(l, hipEventRecord(l->done, l->stream));
     return JSORB_OK;
 }
 

@@ -227,6 +227,21 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
     if (removed) atomicSub(&st[3], removed);
 }
 
+__global__ void k_gather_counts(const int *__restrict__ countsL, const int *__restrict__ countsR, const int *__restrict__ stats,
+                                int32_t *__restrict__ dst, int n_pairs)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_pairs) return;
+    dst[3 * b + 0] = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
+    dst[3 * b + 1] = countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
+    dst[3 * b + 2] = stats[b * 8 + 3];
+}
+
+void launch_gather_counts(const int *countsL, const int *countsR, const int *stats, int32_t *dst, int n_pairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gather_counts, dim3((n_pairs + 255) / 256), dim3(256), 0, s, countsL, countsR, stats, dst, n_pairs);
+}
+
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,

@@ -28,7 +28,7 @@ EXPORTS = [
     "jsorb_copy_descriptors", "jsorb_n_levels", "jsorb_level_dims", "jsorb_level_tiles", "jsorb_total_tiles", "jsorb_scale",
     "jsorb_inv_scale", "jsorb_level_image_device", "jsorb_copy_level_image", "jsorb_copy_tile_candidates", "jsorb_copy_angles",
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
-    "jsorb_copy_stereo", "jsorb_set_stream", "jsorb_get_stream", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
+    "jsorb_copy_stereo", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
     "jsorb_reset_kernel_timing", "jsorb_kernel_name",
 ]
 
@@ -94,8 +94,10 @@ def load_library(path=None):
         "jsorb_stereo_uright_device": (P, [P, I]),
         "jsorb_stereo_depth_device": (P, [P, I]),
         "jsorb_copy_stereo": (I, [P, I, P, P, C.POINTER(JsorbStereoStats)]),
+        "jsorb_gather_counts_async": (I, [P, P, P]),
         "jsorb_set_stream": (I, [P, P]),
         "jsorb_get_stream": (P, [P]),
+        "jsorb_stream_wait_done": (I, [P, P]),
         "jsorb_enable_kernel_timing": (I, [P, I]),
         "jsorb_kernel_time": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
         "jsorb_reset_kernel_timing": (I, [P]),
@@ -273,6 +275,10 @@ class ORBExtractor:
     def set_stream(self, stream_ptr):
         self._chk(self._lib.jsorb_set_stream(self._h, stream_ptr))
 
+    def stream_wait_done(self, other_stream_ptr):
+        """make another HIP stream (raw pointer, 0 = null stream) wait for everything enqueued on this handle"""
+        self._chk(self._lib.jsorb_stream_wait_done(self._h, other_stream_ptr))
+
     def enable_kernel_timing(self, on=True):
         self._chk(self._lib.jsorb_enable_kernel_timing(self._h, int(on)))
 
@@ -312,3 +318,8 @@ def stereo_result(left, image=0):
     st = JsorbStereoStats()
     left._chk(left._lib.jsorb_copy_stereo(left.handle, image, u.ctypes.data, d.ctypes.data, C.byref(st)))
     return u[:n], d[:n], {k: getattr(st, k) for k, _ in JsorbStereoStats._fields_}
+
+
+def gather_counts_async(left, right, dev_dst_ptr):
+    """(N_left, N_right, N_matched) per pair of the last batch -> int32[3*n] DEVICE buffer (payload of the RCCL all_gather)."""
+    left._chk(left._lib.jsorb_gather_counts_async(left.handle, right.handle, dev_dst_ptr))

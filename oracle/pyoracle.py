@@ -61,6 +61,8 @@ def _load(native=False):
         "orc_fast_score_px": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
         "orc_hamming256": (C.c_int, [C.c_void_p, C.c_void_p]),
         "orc_desc_offset": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
+        "orc_bench_pairs": (C.c_long, [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double,
+                                      C.c_int, C.POINTER(C.c_double)]),
         "orc_stereo_match": (C.c_int, [P, P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.POINTER(OrcStereoStats)]),
     }
@@ -198,3 +200,14 @@ def stereo_match(left, right, mb, mbf, th_high=100, th_low=50):
     stats["best_right"] = _arr(left.l.orc_stereo_best_right(left.h), n, np.int32)
     stats["best_dist"] = _arr(left.l.orc_stereo_best_dist(left.h), n, np.int32)
     return u[:n], d[:n], stats
+
+
+def bench_pairs(lefts, rights, mb, mbf, seconds, n_threads, native=True, **kw):
+    """cpu_baseline leg of bench.py: OpenMP over independent pairs, returns (pairs_done, elapsed_s)."""
+    l = lib(native)
+    p = make_params(**kw)
+    lefts = np.ascontiguousarray(lefts, np.uint8)
+    rights = np.ascontiguousarray(rights, np.uint8)
+    el = C.c_double()
+    n = l.orc_bench_pairs(C.byref(p), lefts.ctypes.data, rights.ctypes.data, lefts.shape[0], mb, mbf, seconds, n_threads, C.byref(el))
+    return n, el.value

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def po():
+    """the CPU oracle binding (test infrastructure)"""
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def orb():
+    """the product binding; only GPU tests may create extractors through it"""
+    from jetson_slam_amd import orb as _orb
+    return _orb
+
+
+CONFIGS = {
+    # name: dict(h, w, L, tile, th, fx, bf)  - SURVEY.md 8(d)
+    "tiny": dict(h=120, w=160, L=4, tile=12, th=20, fx=200.0, bf=20.0),
+    "c1": dict(h=240, w=320, L=3, tile=15, th=20, fx=435.2, bf=47.906),
+    "c2": dict(h=480, w=752, L=8, tile=30, th=20, fx=435.2, bf=47.906),
+    "c3": dict(h=376, w=1241, L=8, tile=25, th=60, fx=718.86, bf=386.14),
+    "c5": dict(h=720, w=1280, L=8, tile=20, th=20, fx=435.2, bf=47.906),
+}
+
+
+@pytest.fixture(scope="session")
+def configs():
+    return CONFIGS

@@ -1,0 +1,114 @@
+"""Oracle tables against independent restatements and the values SURVEY.md Appendix B/D derives from the reference."""
+import hashlib
+import math
+import re
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_level_and_tile_geometry_matches_appendix_d(po):
+    # orb_gpu.cpp:55-62, 241-258 evaluated in float32
+    ex = po.OracleExtractor(height=480, width=752, n_levels=8, tile_h=30, tile_w=30)
+    assert ex.level_dims() == [(480, 752), (400, 626), (333, 522), (277, 435), (231, 362), (192, 302), (160, 251), (133, 209)]
+    assert [t[0] for t in ex.tile_dims()] == [30, 25, 20, 17, 14, 12, 10, 8]
+    assert [a * b for a, b in ex.tile_grid()] == [416, 416, 459, 442, 442, 416, 416, 459]
+    assert ex.T == 3466
+    ex = po.OracleExtractor(height=376, width=1241, n_levels=8, tile_h=25, tile_w=25)
+    assert ex.level_dims()[1] == (313, 1034) and ex.T == 6756
+    ex = po.OracleExtractor(height=720, width=1280, n_levels=8, tile_h=20, tile_w=20)
+    assert ex.T == 21053 and sum(h * w for h, w in ex.level_dims()) == 2849345
+    ex = po.OracleExtractor(height=240, width=320, n_levels=3, tile_h=15, tile_w=15)
+    assert ex.level_dims() == [(240, 320), (200, 266), (166, 222)] and ex.T == 1134
+    # fixed_multi_scale_tile_size keeps the level-0 tile everywhere (orb_gpu.cpp:243-247)
+    ex = po.OracleExtractor(height=480, width=752, n_levels=4, tile_h=30, tile_w=30, fixed_tile=True)
+    assert all(t == (30, 30) for t in ex.tile_dims())
+
+
+def test_umax_table(po):
+    # orb_gpu.cpp:161-182 for HALF_PATCH 15 (OpenCV's ORB umax)
+    ex = po.OracleExtractor(height=64, width=64, n_levels=1, tile_h=8, tile_w=8)
+    assert ex.umax().tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    # the product kernel hard-codes the same table as packed nibbles (k_describe.hip umax15)
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_describe.hip")).read()
+    tab = int(re.search(r"tab = (0x[0-9A-Fa-f]+)ull", src).group(1), 16)
+    assert [(tab >> (4 * v)) & 0xF for v in range(16)] == ex.umax().tolist()
+
+
+def test_gauss_weights_definition(po):
+    # orb_gpu.cpp:196-220 with the definition adopted in SURVEY A.2: RN_f32(exp_double(arg)), f32 sum, f32 divide
+    ex = po.OracleExtractor(height=64, width=64, n_levels=1, tile_h=8, tile_w=8)
+    w = ex.gauss_weights()
+    g = np.zeros(49, np.float32)
+    s = np.float32(0)
+    k = 0
+    for j in range(-3, 4):
+        for kk in range(-3, 4):
+            arg = np.float32(-(j * j + kk * kk)) / np.float32(200.0)
+            g[k] = np.float32(math.exp(float(arg)))
+            s = np.float32(s + g[k])
+            k += 1
+    assert s.view(np.uint32) == 0x423C5F01
+    g = (g / s).astype(np.float32)
+    assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    # the HIP kernel embeds the same bit patterns
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur.hip")).read()
+    for b in sorted(set(w.view(np.uint32).tolist())):
+        assert ("0x%08X" % b) in src
+
+
+def _lut_bruteforce(nmin, nmax):
+    """independent restatement of orb_gpu.cpp:377-431 on bit strings"""
+    out = np.zeros(65536, np.uint8)
+    for j in range(65536):
+        bits = [(j >> (15 - k)) & 1 for k in range(16)]     # scan order: bit 15 first
+        run, ok, decided = 0, False, False
+        for b in bits:
+            if b:
+                run += 1
+            else:
+                if nmin <= run <= nmax:
+                    ok, decided = True, True
+                    break
+                run = 0
+        if not decided:
+            lead = 0
+            for b in bits:
+                if not b:
+                    break
+                lead += 1
+            ok = nmin <= run + lead <= nmax
+        out[j] = ok
+    return out
+
+
+@pytest.mark.parametrize("nmin,nmax", [(9, 14), (9, 16), (12, 12)])
+def test_fast_lut_matches_bruteforce(po, nmin, nmax):
+    ex = po.OracleExtractor(height=64, width=64, n_levels=1, tile_h=8, tile_w=8, fast_n_min=nmin, fast_n_max=nmax)
+    lut = ex.lut()
+    assert np.array_equal(lut, _lut_bruteforce(nmin, nmax))
+    assert lut[0xFFFF] == 0 and lut[0] == 0            # Appendix C-3
+    # a clean arc of length n inside the word is accepted iff nmin <= n <= nmax (bounded arc, Appendix B / F5)
+    for n in range(1, 16):
+        assert lut[((1 << n) - 1) << 1] == (nmin <= n <= nmax)
+
+
+def test_pattern_tables_identical_and_hashed():
+    a = open(os.path.join(ROOT, "oracle", "orb_pattern.inc")).read()
+    b = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "orb_pattern.inc")).read()
+    assert a == b
+    def vals(tag):
+        body = a[a.index("#define " + tag) + len("#define " + tag):]
+        body = body[:body.index("#define")] if "#define" in body else body
+        return [int(t) for t in re.findall(r"-?\d+", body.replace("\\", " "))]
+    xs, ys = vals("JSORB_PATTERN_X_VALUES"), vals("JSORB_PATTERN_Y_VALUES")
+    assert len(xs) == 512 and len(ys) == 512
+    digest = hashlib.sha256(bytes((t & 0xFF) for t in xs + ys)).hexdigest()
+    assert digest in a
+    # OpenCV's bit_pattern_31_ starts 8,-3, 9,5, 4,2, 7,-12 and ends -1,-6, 0,-11
+    assert (xs[0], ys[0], xs[1], ys[1], xs[2], ys[2], xs[3], ys[3]) == (8, -3, 9, 5, 4, 2, 7, -12)
+    assert (xs[510], ys[510], xs[511], ys[511]) == (-1, -6, 0, -11)
+    assert max(map(abs, xs + ys)) == 13
