@@ -1,0 +1,54 @@
+// stereo_frame.cpp - the Frame stereo constructor's front-end half (Frame.cpp:80-250) written against the compat shim:
+// two ORBExtractor objects run from two std::threads, SyncedMem::to_cpu(), SoA unpack, ComputeStereoMatches.
+// Usage: stereo_frame H W L tile th fx bf left.raw right.raw out.bin
+// out.bin: int32 N_l, N_r, then kp_l[6N_l] desc_l[32N_l] kp_r[6N_r] desc_r[32N_r] uRight[N_l] depth[N_l]
+// Build: g++ -std=c++17 -I include examples/stereo_frame.cpp -L jetson_slam_amd -ljsorb -lpthread
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "jsorb_compat.hpp"
+
+static std::vector<unsigned char> read_raw(const char *path, size_t n)
+{
+    std::vector<unsigned char> v(n);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(v.data(), 1, n, f) != n) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 11) { fprintf(stderr, "usage: %s H W L tile th fx bf left.raw right.raw out.bin\n", argv[0]); return 2; }
+    const int H = atoi(argv[1]), W = atoi(argv[2]), L = atoi(argv[3]), tile = atoi(argv[4]), th = atoi(argv[5]);
+    const float fx = (float)atof(argv[6]), mbf = (float)atof(argv[7]);
+    auto imL = read_raw(argv[8], (size_t)H * W), imR = read_raw(argv[9], (size_t)H * W);
+    try {
+        Jetson_SLAM::ORBExtractor exL(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
+        Jetson_SLAM::ORBExtractor exR(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
+        orb_cuda::SyncedMem<int> kpL, kpR;
+        orb_cuda::SyncedMem<unsigned char> dL, dR;
+        std::thread tl([&] { exL.extract(imL.data(), W, kpL, dL); });   // Frame.cpp:107-110
+        std::thread tr([&] { exR.extract(imR.data(), W, kpR, dR); });
+        tl.join(); tr.join();
+        kpL.to_cpu(); kpR.to_cpu(); dL.to_cpu(); dR.to_cpu();           // Frame.cpp:119-122
+        std::vector<float> mvuRight, mvDepth;
+        Jetson_SLAM::ComputeStereoMatches(exL, exR, mbf / fx, mbf, mvuRight, mvDepth);
+        const int nl = kpL.count_ / 6, nr = kpR.count_ / 6;
+        FILE *f = fopen(argv[10], "wb");
+        fwrite(&nl, 4, 1, f); fwrite(&nr, 4, 1, f);
+        fwrite(kpL.cpu_data(), 4, 6 * (size_t)nl, f); fwrite(dL.cpu_data(), 1, 32 * (size_t)nl, f);
+        fwrite(kpR.cpu_data(), 4, 6 * (size_t)nr, f); fwrite(dR.cpu_data(), 1, 32 * (size_t)nr, f);
+        fwrite(mvuRight.data(), 4, nl, f); fwrite(mvDepth.data(), 4, nl, f);
+        fclose(f);
+        int matched = 0;
+        for (float d : mvDepth) matched += d > 0;
+        printf("N_left=%d N_right=%d matched=%d levels=%d\n", nl, nr, matched, exL.get_levels());
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

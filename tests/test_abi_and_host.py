@@ -93,3 +93,14 @@ def test_shard_ranges_partition_the_batch():
                 assert 0 <= a <= b <= n and b - a <= max_shard(n, world)
                 cover += list(range(a, b))
             assert cover == list(range(n))
+
+
+def test_cpp_compat_shim_compiles_and_links(libpath, tmp_path):
+    """include/jsorb_compat.hpp recreates ORBExtractor / SyncedMem / ComputeStereoMatches; the example must compile with plain
+    g++ (no HIP or OpenCV headers) and link against libjsorb.so."""
+    import subprocess
+    exe = str(tmp_path / "stereo_frame")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "stereo_frame.cpp"), "-L", os.path.dirname(libpath), "-ljsorb",
+                           "-lpthread", "-Wl,-rpath," + os.path.dirname(libpath), "-o", exe])
+    assert os.path.exists(exe)
