@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
+    ap.add_argument("--single-stream", action="store_true", help="left and right handles share one HIP stream (clean per-kernel times)")
     args = ap.parse_args()
 
     import torch
@@ -102,6 +103,11 @@ def main():
     # each handle keeps its own HIP stream: left and right extraction overlap (the reference runs them in two host threads),
     # the stereo kernel on the left stream waits for the right stream's event.
     torch_stream_ptr = torch.cuda.current_stream(dev).cuda_stream
+    shared_stream = None
+    if args.single_stream:
+        shared_stream = torch.cuda.Stream(dev)
+        exl.set_stream(shared_stream.cuda_stream)
+        exr.set_stream(shared_stream.cuda_stream)
     counts_d = torch.zeros(P * 3, dtype=torch.int32, device=dev)
     gathered = [torch.zeros_like(counts_d) for _ in range(world)] if world > 1 else None
     mb = bf / fx

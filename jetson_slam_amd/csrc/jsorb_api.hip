@@ -40,7 +40,7 @@ struct jsorb_extractor {
     hipEvent_t done = nullptr;         // recorded after the last enqueued work of this handle
     hipEvent_t readers_done = nullptr; // recorded on ANOTHER handle's stream after it finished reading this handle's buffers
     bool has_readers = false;
-    size_t detect_lds = 0;
+    size_t detect_lds = 0, pyr_lds = 0;
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
     uint32_t *lut_bits = nullptr;
@@ -51,6 +51,7 @@ struct jsorb_extractor {
     int32_t *out_kp = nullptr;
     float *st_u = nullptr, *st_d = nullptr;
     int *st_l1 = nullptr, *st_stats = nullptr;
+    unsigned *st_aux = nullptr;
     // pinned host mirrors
     int *h_counts = nullptr, *h_stats = nullptr;
     ImageSrc src{};            // where level 0 of the last extract lives
@@ -138,9 +139,9 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         if (lv.blur_bx == 0 || lv.blur_by == 0) { lv.blur_bx = 1; lv.blur_by = 0; }
         lv.blur_blk0 = bblk;
         bblk += lv.blur_bx * lv.blur_by;
-        lv.pyr_bx = (lv.W + 255) / 256;
+        lv.pyr_bx = (lv.W + 127) / 128;          // k_pyramid: 128 x 8 output tile per workgroup
         lv.pyr_blk0 = pblk;
-        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + 3) / 4);
+        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + 7) / 8);
     }
     g.T = tiles;
     if (tiles >= (1 << 20)) { err = "too many tiles"; return JSORB_ERR_INVALID; }
@@ -216,7 +217,7 @@ int run_pipeline(jsorb_extractor *e, int n)
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->readers_done, 0));
         e->has_readers = false;
     }
-    TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, n, e->stream));
+    TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, n, e->pyr_lds, e->stream));
     TIMED(e, JSORB_K_DETECT, launch_detect(g, e->src, e->slab, e->mask, e->lut_bits, e->tile_out, n, e->detect_lds, e->stream));
     TIMED(e, JSORB_K_COMPACT, launch_compact(g, e->tile_out, e->kp, e->counts, e->row_tab, n, e->stream));
     TIMED(e, JSORB_K_BLUR, launch_blur(g, e->src, e->slab, e->blur, n, e->stream));
@@ -268,6 +269,8 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipEventCreateWithFlags(&e->readers_done, hipEventDisableTiming));
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
+    e->pyr_lds = pyramid_lds_bytes(g);
+    if (e->pyr_lds > 160 * 1024) { e->err = "pyramid scale too large for the LDS-staged resampler"; return JSORB_ERR_INVALID; }
     const size_t B = (size_t)e->B, T = (size_t)g.T;
     const size_t slab_total = B * g.slab_bytes + 4096;
     HIPCHK(e, hipMalloc(&e->slab, slab_total));
@@ -285,6 +288,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipMalloc(&e->st_u, B * T * 4));
     HIPCHK(e, hipMalloc(&e->st_d, B * T * 4));
     HIPCHK(e, hipMalloc(&e->st_l1, B * T * 4));
+    HIPCHK(e, hipMalloc(&e->st_aux, B * T * 4));
     HIPCHK(e, hipMalloc(&e->st_stats, B * 8 * sizeof(int)));
     HIPCHK(e, hipMemset(e->counts, 0, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
     HIPCHK(e, hipHostMalloc(&e->h_counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
@@ -325,7 +329,7 @@ void jsorb_destroy(jsorb_extractor *e)
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
@@ -519,8 +523,8 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     sa.th_orb = (th_high + th_low) / 2;
     HIPCHK(l, hipMemsetAsync(l->st_stats, 0, sizeof(int) * 8 * n, l->stream));
     TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts,
-                                          r->desc, r->row_tab, l->st_u, l->st_d, l->st_l1, l->st_stats, sa, n, l->stream));
-    TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts, l->st_u, l->st_d, l->st_l1, l->st_stats, n, l->stream));
+                                          r->desc, r->row_tab, l->st_u, l->st_d, l->st_l1, l->st_aux, sa, n, l->stream));
+    TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts, l->st_u, l->st_d, l->st_l1, l->st_aux, l->st_stats, n, l->stream));
     HIPCHK(l, hipGetLastError());
     HIPCHK(l, hipMemcpyAsync(l->h_stats, l->st_stats, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, l->stream));
     HIPCHK(l, hipEventRecord(l->done, l->stream));

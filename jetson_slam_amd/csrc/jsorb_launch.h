@@ -18,7 +18,8 @@ struct StereoArgs {
 // dynamic LDS bytes the detect kernel needs for the given geometry (max over levels)
 size_t detect_lds_bytes(const Geometry &g);
 
-void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, int n_images, hipStream_t s);
+size_t pyramid_lds_bytes(const Geometry &g);
+void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, int n_images, size_t lds_bytes, hipStream_t s);
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
@@ -30,9 +31,9 @@ void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
-                   float *u_right, float *depth, int *best_l1, int *stats, StereoArgs a, int n_pairs, hipStream_t s);
+                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s);
 void launch_gather_counts(const int *countsL, const int *countsR, const int *stats, int32_t *dst, int n_pairs, hipStream_t s);
-void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, int *stats,
-                   int n_pairs, hipStream_t s);
+void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
+                   int *stats, int n_pairs, hipStream_t s);
 
 } // namespace jsorb

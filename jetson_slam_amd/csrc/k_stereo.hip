@@ -25,16 +25,26 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-__global__ __launch_bounds__(256) void k_stereo(Geometry g, ImageSrc srcL, const uint8_t *slabL, ImageSrc srcR, const uint8_t *slabR,
-                                                const int32_t *__restrict__ outL, const int *__restrict__ countsL, const uint8_t *__restrict__ descL,
-                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
-                                                const int *__restrict__ row_tabR,
-                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
-                                                int *__restrict__ stats, StereoArgs sa)
+// One wave64 (= one 64-thread workgroup) per left keypoint.
+//  * candidate phase: the <=3 octave ranges are merged into one flat index space so that consecutive lanes read consecutive
+//    right keypoints (coordinates and 32-byte descriptors: fully coalesced) and the dependent-load chain is paid once;
+//  * L1 phase: the 11x16 B left window and the 11x32 B right search band are staged in LDS with 3 coalesced dword-load
+//    instructions (the divergent byte gathers of a per-pixel formulation are what bound the first version: the vector
+//    memory pipeline handled ~1 lane/clk); 121 (row, shift) tasks then accumulate |(L-Lc)-(R-Rc)| from LDS and are
+//    reduced with 11 LDS atomics.
+__global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const uint8_t *slabL, ImageSrc srcR, const uint8_t *slabR,
+                                               const int32_t *__restrict__ outL, const int *__restrict__ countsL, const uint8_t *__restrict__ descL,
+                                               const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
+                                               const int *__restrict__ row_tabR,
+                                               float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
+                                               unsigned *__restrict__ aux, StereoArgs sa)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned s_left[11 * 4];
+    __shared__ unsigned s_right[11 * 8];
+    __shared__ int s_acc[12];
+    const int lane = threadIdx.x;
     const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + wave;
+    const int i = blockIdx.x;
     const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     const int Nr = countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     if (i >= Nl) return;
@@ -52,31 +62,45 @@ __global__ __launch_bounds__(256) void k_stereo(Geometry g, ImageSrc srcL, const
         const uint4 a0 = dl[0], a1 = dl[1];
         const int vLi = (int)vL;
         const int *rt = row_tabR + (size_t)b * g.row_tab_len;
-        for (int lr = levelL - 1; lr <= levelL + 1; lr++) {
-            if (lr < 0 || lr >= g.L) continue;
-            const LevelDesc &lv = g.lv[lr];
-            const float r = 2.0f * lv.scale;
-            // conservative tile-row window of level lr (exact tests follow per candidate)
-            int lo = (int)__builtin_floorf((vL - r - 1.0f) / lv.scale) - 1;
-            int hi = (int)__builtin_ceilf((vL + r + 2.0f) / lv.scale) + 1;
-            int t_lo = lo < 0 ? 0 : lo / lv.th;
-            int t_hi = hi < 0 ? -1 : hi / lv.th;
-            if (t_hi > lv.nth - 1) t_hi = lv.nth - 1;
-            if (t_lo > t_hi) continue;
-            const int j0 = rt[lv.row_tab_off + t_lo], j1 = rt[lv.row_tab_off + t_hi + 1];
-            for (int j = j0 + lane; j < j1; j += 64) {
-                const float kpY = (float)oR[Nr + j];
-                const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
-                if (vLi < minr || vLi > maxr) continue;
-                const float uR = (float)oR[j];
-                if (!(uR >= minU && uR <= maxU)) continue;
-                n_cand++;
-                const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + j) * 32);
-                const int d = hamming256(a0, a1, dr[0], dr[1]);
-                if (d < sa.th_high) {
-                    const unsigned key = ((unsigned)d << 20) | (unsigned)j;
-                    best_key = key < best_key ? key : best_key;
+        int j0[3], len[3];
+        float rr[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int lr = levelL - 1 + t;
+            j0[t] = 0; len[t] = 0; rr[t] = 0.f;
+            if (lr >= 0 && lr < g.L) {
+                const LevelDesc &lv = g.lv[lr];
+                const float r = 2.0f * lv.scale;
+                rr[t] = r;
+                // conservative tile-row window of level lr (exact tests follow per candidate)
+                const int lo = (int)__builtin_floorf((vL - r - 1.0f) / lv.scale) - 1;
+                const int hi = (int)__builtin_ceilf((vL + r + 2.0f) / lv.scale) + 1;
+                const int t_lo = lo < 0 ? 0 : lo / lv.th;
+                int t_hi = hi < 0 ? -1 : hi / lv.th;
+                if (t_hi > lv.nth - 1) t_hi = lv.nth - 1;
+                if (t_lo <= t_hi) {
+                    j0[t] = rt[lv.row_tab_off + t_lo];
+                    len[t] = rt[lv.row_tab_off + t_hi + 1] - j0[t];
                 }
+            }
+        }
+        const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
+        for (int k = lane; k < total; k += 64) {
+            const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
+            const int j = (t == 2 ? j0[2] - c2 : (t == 1 ? j0[1] - c1 : j0[0])) + k;
+            const float r = t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]);
+            const float kpY = (float)oR[Nr + j];
+            const float uR = (float)oR[j];
+            const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + j) * 32);
+            const uint4 b0 = dr[0], b1 = dr[1];
+            const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
+            if (vLi < minr || vLi > maxr) continue;
+            if (!(uR >= minU && uR <= maxU)) continue;
+            n_cand++;
+            const int d = hamming256(a0, a1, b0, b1);
+            if (d < sa.th_high) {
+                const unsigned key = ((unsigned)d << 20) | (unsigned)j;
+                best_key = key < best_key ? key : best_key;
             }
         }
     }
@@ -85,7 +109,7 @@ __global__ __launch_bounds__(256) void k_stereo(Geometry g, ImageSrc srcL, const
 
     float out_u = -1.0f, out_d = -1.0f;
     int out_l1 = -1, corr = 0;
-    if (best_key != 0xFFFFFFFFu && (int)(best_key >> 20) < sa.th_orb) {
+    if (best_key != 0xFFFFFFFFu && (int)(best_key >> 20) < sa.th_orb) {     // workgroup-uniform
         const int bestIdxR = (int)(best_key & 0xFFFFFu);
         const LevelDesc &lv = g.lv[levelL];
         const float uR0 = (float)oR[bestIdxR];
@@ -98,29 +122,45 @@ __global__ __launch_bounds__(256) void k_stereo(Geometry g, ImageSrc srcL, const
             corr = 1;
             const int xl = (int)scaleduL0, xr = (int)scaleduR0, y = (int)scaledvL0;
             int pl, pr;
-            const uint8_t *li = level_ptr(g, srcL, slabL, b, levelL, pl) + (size_t)y * pl + xl;
-            const uint8_t *ri = level_ptr(g, srcR, slabR, b, levelL, pr) + (size_t)y * pr + xr;
-            const int lc = li[0];
-            int acc[11];
-#pragma unroll
-            for (int s = 0; s < 11; s++) acc[s] = 0;
-#pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
-                const int idx = pass * 64 + lane;
-                if (idx < 121) {
-                    const int wh = idx / 11 - 5, ww = idx % 11 - 5;
-                    const int lval = (int)li[wh * pl + ww] - lc;
-                    const uint8_t *rrow = ri + wh * pr + ww;
-#pragma unroll
-                    for (int s = 0; s < 11; s++) {
-                        const int rval = (int)rrow[s - 5] - (int)ri[s - 5];
-                        const int df = lval - rval;
-                        acc[s] += df < 0 ? -df : df;
-                    }
-                }
+            const uint8_t *imL = level_ptr(g, srcL, slabL, b, levelL, pl);
+            const uint8_t *imR = level_ptr(g, srcR, slabR, b, levelL, pr);
+            const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;      // dword aligned window starts
+            if (lane < 44) {
+                const int row = lane >> 2, dw = lane & 3;
+                const int x = la + 4 * dw;
+                s_left[lane] = (x + 4 <= pl) ? *reinterpret_cast<const unsigned *>(imL + (size_t)(y - 5 + row) * pl + x) : 0u;
             }
 #pragma unroll
-            for (int s = 0; s < 11; s++) acc[s] = wave_sum_i32(acc[s]);
+            for (int t = lane; t < 88; t += 64) {
+                const int row = t >> 3, dw = t & 7;
+                const int x = ra + 4 * dw;
+                s_right[t] = (x + 4 <= pr) ? *reinterpret_cast<const unsigned *>(imR + (size_t)(y - 5 + row) * pr + x) : 0u;
+            }
+            if (lane < 11) s_acc[lane] = 0;
+            __syncthreads();
+            const unsigned char *bl = reinterpret_cast<const unsigned char *>(s_left) + (xl - 5 - la);
+            const unsigned char *br = reinterpret_cast<const unsigned char *>(s_right) + (xr - 10 - ra);
+            const int lc = bl[5 * 16 + 5];
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int q = pass * 64 + lane;
+                if (q < 121) {
+                    const int row = q / 11, s = q - row * 11;
+                    const int rc = br[5 * 32 + 5 + s];
+                    const unsigned char *pL = bl + row * 16, *pR = br + row * 32 + s;
+                    int part = 0;
+#pragma unroll
+                    for (int c = 0; c < 11; c++) {
+                        const int df = ((int)pL[c] - lc) - ((int)pR[c] - rc);
+                        part += df < 0 ? -df : df;
+                    }
+                    atomicAdd(&s_acc[s], part);
+                }
+            }
+            __syncthreads();
+            int acc[11];
+#pragma unroll
+            for (int s = 0; s < 11; s++) acc[s] = s_acc[s];
             int bestDist = 0x7FFFFFFF, bestR = 0;
 #pragma unroll
             for (int s = 0; s < 11; s++)
@@ -151,31 +191,41 @@ __global__ __launch_bounds__(256) void k_stereo(Geometry g, ImageSrc srcL, const
         u_right[tb + i] = out_u;
         depth[tb + i] = out_d;
         best_l1[tb + i] = out_l1;
-        int *st = stats + b * 8;
-        if (n_cand) atomicAdd(&st[0], n_cand);
-        if (corr) atomicAdd(&st[1], 1);
-        if (out_l1 >= 0) atomicAdd(&st[2], 1);
+        // per-keypoint statistics; k_median reduces them per pair (per-wave global atomics on one cache line per pair
+        // serialised at the L2 atomic unit and cost more than the whole matcher)
+        aux[tb + i] = (n_cand & 0x7FFFFFFF) | (corr ? 0x80000000u : 0u);
     }
 }
 
 // 2.1 x median cut (orb_stereo_match.cu:563-578).  The median of the sorted (dist, idx) pairs is the (nv/2)-th smallest
 // distance; L1 distances are < 2^16 (121*510), so a two-pass 256-bin radix select in LDS finds it exactly.
 __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restrict__ countsL, float *__restrict__ u_right,
-                                                float *__restrict__ depth, const int *__restrict__ best_l1, int *__restrict__ stats)
+                                                float *__restrict__ depth, const int *__restrict__ best_l1,
+                                                const unsigned *__restrict__ aux, int *__restrict__ stats)
 {
     __shared__ int hist[256];
     __shared__ int sel[4];
+    __shared__ int s_cand, s_corr;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     const size_t tb = (size_t)b * g.T;
     int *st = stats + b * 8;
     hist[tid] = 0;
+    if (tid == 0) { s_cand = 0; s_corr = 0; }
     __syncthreads();
+    int cand = 0, corr = 0;
     for (int i = tid; i < Nl; i += 256) {
         const int d = best_l1[tb + i];
         if (d >= 0) atomicAdd(&hist[(d >> 8) & 255], 1);
+        const unsigned a = aux[tb + i];
+        cand += (int)(a & 0x7FFFFFFFu);
+        corr += (int)(a >> 31);
     }
+    cand = wave_sum_i32(cand);
+    corr = wave_sum_i32(corr);
+    if ((tid & 63) == 0) { atomicAdd(&s_cand, cand); atomicAdd(&s_corr, corr); }
     __syncthreads();
+    if (tid == 0) { st[0] = s_cand; st[1] = s_corr; }
     if (tid == 0) {
         int nv = 0;
         for (int k = 0; k < 256; k++) nv += hist[k];
@@ -190,6 +240,7 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
     }
     __syncthreads();
     const int nv = sel[2];
+    if (tid == 0) st[2] = nv;
     if (nv == 0) {              // Appendix C-6: nothing matched -> no cut
         if (tid == 0) st[3] = 0;
         return;
@@ -245,16 +296,16 @@ void launch_gather_counts(const int *countsL, const int *countsR, const int *sta
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
-                   float *u_right, float *depth, int *best_l1, int *stats, StereoArgs a, int n_pairs, hipStream_t s)
+                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_stereo, dim3((g.T + 3) / 4, n_pairs), dim3(256), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
-                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, stats, a);
+    hipLaunchKernelGGL(k_stereo, dim3(g.T, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
+                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a);
 }
 
-void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, int *stats,
-                   int n_pairs, hipStream_t s)
+void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
+                   int *stats, int n_pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_median, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, stats);
+    hipLaunchKernelGGL(k_median, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, aux, stats);
 }
 
 } // namespace jsorb
