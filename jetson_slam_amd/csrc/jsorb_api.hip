@@ -127,7 +127,7 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         lv.log2_tw = 0;
         while ((1 << lv.log2_tw) < lv.tw) lv.log2_tw++;
         // this build's workgroup tables
-        lv.k_tiles = std::max(1, 126 / lv.tw);
+        lv.k_tiles = std::max(1, 122 / lv.tw);   // k*tw + 2 <= 124: a score-region row fits 32 aligned LDS dwords (k_detect phase 1)
         lv.groups_per_row = (lv.ntw - 1) / lv.k_tiles + 1;
         lv.detect_blk0 = dblk;
         dblk += lv.nth * lv.groups_per_row;
@@ -262,6 +262,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (rc) return rc;
     Geometry &g = e->g;
     g.has_mask = mask ? 1 : 0;
+    if (const char *d = getenv("JSORB_DBG_STOP")) g.dbg_stop = atoi(d);
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
@@ -381,7 +382,7 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     if (!e || !dev_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
-    const bool in_place = (step % 4 == 0) && (((uintptr_t)dev_images) % 4 == 0) && (image_stride % 4 == 0);
+    const bool in_place = (step % 16 == 0) && (((uintptr_t)dev_images) % 16 == 0) && (image_stride % 16 == 0);   // kernels stage with 16-byte loads
     if (in_place) {   // level 0 is read where it lies: no copy of the grayscale plane
         e->src.l0 = dev_images; e->src.l0_stride = image_stride; e->src.l0_pitch = step;
     } else {

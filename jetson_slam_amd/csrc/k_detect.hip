@@ -12,8 +12,11 @@
 //      layout: within a column by (ty, k) = ((y - r*th) % n_ty, (y - r*th) / n_ty) lexicographic, across columns
 //      by the ceil-halving tree over shared memory including its stale-slot re-reads.
 // MI355X design:
-//   * phase 1 (all pixels): the two early rejects, 5 LDS byte reads per pixel.  Survivors (typically < 15 %) are
-//     compacted into an LDS work list with wave64 __ballot + popcount prefix, so phase 2 runs on dense waves.
+//   * phase 0: the image tile is staged with 16-byte global loads / ds_write_b128 (a CU retires one vector-memory
+//     wave-instruction per ~16 clk whatever its width; 4-byte loads capped the first version at ~1.5 TB/s).
+//   * phase 1 (all pixels): the two early rejects, branch-free, 4 pixels per lane from 5 aligned LDS dwords.  Survivors
+//     (~18 % on the benchmark images) are compacted into per-wave LDS work lists with wave64 __ballot + popcount
+//     prefixes (no atomics), so phase 2 runs on dense waves.
 //   * phase 2 (survivors): 16-pixel ring, LUT bit test (8 KB bit table, L1/L2 resident), SAD score -> LDS.
 //   * phase 3 (survivors with score > 0): 3x3 NMS from LDS and one ds_max_u32 per column with the key
 //     (score << 16 | 0xFFFF - rank), rank = ty * mini_tile + k : the max key IS the reference's column winner.
@@ -23,10 +26,11 @@
 namespace jsorb {
 
 struct DetectLds {
-    int img_stride;      // bytes per LDS image row
+    int img_stride;      // bytes per LDS image row (multiple of 16)
     int img_rows;        // th + 8
     int score_w;         // k*tw + 2
     int score_rows;      // th + 2
+    int list_cap;        // survivor-list capacity of ONE wave (entries)
     size_t off_score, off_list, off_colkey, off_tree, off_count, total;
 };
 
@@ -34,24 +38,25 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
 {
     DetectLds d;
     const int ktw = k_tiles * tw;
-    d.img_stride = ((ktw + 8 + 3 + 3) & ~3) + 4;   // window is dword aligned on the left: up to 3 extra bytes
+    d.img_stride = ((ktw + 8 + 15 + 15) & ~15);    // window is 16-byte aligned on the left: up to 15 extra bytes
     d.img_rows = th + 8;
     d.score_w = ktw + 2;
     d.score_rows = th + 2;
+    d.list_cap = 2 * ((d.score_rows + 7) / 8) * d.score_w;      // a wave owns <= 2*ceil(rows/8) rows of the score region
     size_t o = (size_t)d.img_stride * d.img_rows;
     o = (o + 15) & ~(size_t)15;
     d.off_score = o;
     o += (size_t)d.score_w * d.score_rows * 2;
     o = (o + 15) & ~(size_t)15;
     d.off_list = o;
-    o += (size_t)d.score_w * d.score_rows * 2;
+    o += (size_t)d.list_cap * 4 * 2;
     o = (o + 15) & ~(size_t)15;
     d.off_colkey = o;
     o += 128 * 4;
     d.off_tree = o;
     o += 128 * 8;
     d.off_count = o;
-    o += 16;
+    o += 32;
     d.total = o;
     return d;
 }
@@ -65,6 +70,9 @@ size_t detect_lds_bytes(const Geometry &g)
     }
     return m;
 }
+
+// |a - v| <= th  <=>  (unsigned)(a - (v - th)) <= 2*th
+#define NEAR(a, vmt, th2) ((unsigned)((a) - (vmt)) <= (th2))
 
 __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out)
@@ -90,70 +98,92 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
     unsigned *s_colkey = reinterpret_cast<unsigned *>(smem + L.off_colkey);
     unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
-    int *s_count = reinterpret_cast<int *>(smem + L.off_count);
+    int *s_count = reinterpret_cast<int *>(smem + L.off_count);     // [4] survivors per wave
 
     int pitch;
     const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
 
-    // ---- phase 0: stage image rows [y0-4, y0+th+4) x cols [xs, xs+4*nd) ; zero the score tile ----
-    const int xs = (xg0 - 4) & ~3;                        // dword aligned (may be negative)
-    const int nd = L.img_stride >> 2;
-    for (int i = tid; i < L.img_rows * nd; i += 256) {
-        const int ly = i / nd, dx = i - ly * nd;
-        const int y = y0 - 4 + ly, x = xs + 4 * dx;
-        unsigned v = 0;
-        if (y >= 0 && y < H && x >= 0 && x + 4 <= pitch) v = *reinterpret_cast<const unsigned *>(img + (size_t)y * pitch + x);
-        reinterpret_cast<unsigned *>(s_img)[ly * nd + dx] = v;
+    // ---- phase 0: stage image rows [y0-4, y0+th+4) x cols [xs, xs+S) with 16-byte loads ; zero the score tile ----
+    // (4-byte loads cap a CU at ~1/4 of its HBM rate: the vector-memory pipeline retires one wave-instruction per
+    //  ~16 clk whatever its width, so staging uses global_load_dwordx4 / ds_write_b128 throughout)
+    const int S = L.img_stride;
+    const int xs = (xg0 - 4) & ~15;                       // 16-byte aligned (may be negative)
+    const int nq16 = S >> 4;
+    for (int i = tid; i < L.img_rows * nq16; i += 256) {
+        const int ly = i / nq16, dx = i - ly * nq16;
+        const int y = y0 - 4 + ly, x = xs + 16 * dx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y >= 0 && y < H && x >= 0 && x + 16 <= pitch) v = *reinterpret_cast<const uint4 *>(img + (size_t)y * pitch + x);
+        reinterpret_cast<uint4 *>(s_img)[i] = v;
     }
     {
-        const int nsc = (L.score_w * L.score_rows + 1) >> 1;
-        unsigned *z = reinterpret_cast<unsigned *>(s_score);
-        for (int i = tid; i < nsc; i += 256) z[i] = 0;
+        const int nsc = (L.score_w * L.score_rows * 2 + 15) >> 4;
+        uint4 *z = reinterpret_cast<uint4 *>(s_score);
+        for (int i = tid; i < nsc; i += 256) z[i] = make_uint4(0, 0, 0, 0);
         if (tid < 128) s_colkey[tid] = 0;
-        if (tid == 0) *s_count = 0;
     }
     __syncthreads();
+    if (g.dbg_stop == 1) return;
 
-    // ---- phase 1: early rejects on every pixel of the (th+2) x (ktw+2) score region ----
+    // ---- phase 1: the two early rejects on every pixel of the (th+2) x (ktw+2) score region, 4 pixels per lane ----
+    // LDS column c <-> image x = xs + c ; region column rx <-> c = c0 + rx.  A lane owns one aligned LDS dword (4 pixels)
+    // and reads 5 dwords (left/centre/right, row-3, row+3); a wave covers two region rows per step when a row fits in 32
+    // dwords.  Survivors go to a per-wave list (no atomics): 4 ballots + popcount prefix per step.
     const int threshold = g.threshold;
-    const int lx_off = (xg0 - 1) - xs;                    // LDS column of region column 0
+    const unsigned th2 = 2u * (unsigned)threshold;
+    const int c0 = (xg0 - 1) - xs;                        // LDS column of region column 0   (3 <= c0 <= 18)
+    const int q0 = c0 >> 2;
+    const int nq = ((c0 + L.score_w - 1) >> 2) - q0 + 1;  // dwords per region row
+    const int c_lo = max(c0, JSORB_BORDER - xs), c_hi = min(c0 + L.score_w, W - JSORB_BORDER - xs);
+    const unsigned c_span = c_hi > c_lo ? (unsigned)(c_hi - c_lo) : 0u;
     const uint8_t *mask = g.has_mask ? mask_slab + lv.img_off : nullptr;
-    for (int ry = wave; ry < L.score_rows; ry += 4) {
+    const int two_rows = nq <= 32 ? 1 : 0;
+    const int sub = two_rows ? (lane >> 5) : 0;
+    const int q = two_rows ? (lane & 31) : lane;
+    const int rows_per_step = two_rows ? 2 : 1;
+    unsigned short *my_list = s_list + wave * L.list_cap;
+    int n_mine = 0;                                       // wave-uniform
+    for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += 4 * rows_per_step) {
+        const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
-        if (y < JSORB_BORDER || y >= H - JSORB_BORDER) continue;     // wave-uniform
-        const unsigned char *row = s_img + (ry + 3) * L.img_stride + lx_off;
-        for (int rx0 = 0; rx0 < L.score_w; rx0 += 64) {
-            const int rx = rx0 + lane;
-            const int x = xg0 - 1 + rx;
-            bool pass = false;
-            if (rx < L.score_w && x >= JSORB_BORDER && x < W - JSORB_BORDER) {
-                bool m = true;
-                if (mask) m = mask[(size_t)y * lv.pitch + x] != 0;
-                if (m) {
-                    const int v = row[rx], vt = v + threshold, v_t = v - threshold;
-                    const int p4 = row[rx + 3], p12 = row[rx - 3];
-                    if (!(p4 <= vt && p4 >= v_t && p12 <= vt && p12 >= v_t)) {
-                        const int p0 = row[rx + 3 * L.img_stride], p8 = row[rx - 3 * L.img_stride];
-                        pass = !(p0 <= vt && p0 >= v_t && p8 <= vt && p8 >= v_t);
-                    }
-                }
-            }
-            const unsigned long long bal = __ballot(pass);
-            if (bal) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(s_count, __popcll(bal));
-                base = __shfl(base, 0, 64);
-                if (pass) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((ry << 8) | rx);
-            }
+        const bool row_ok = ry < L.score_rows && y >= JSORB_BORDER && y < H - JSORB_BORDER && q < nq;
+        const int qq = row_ok ? q0 + q : q0;              // keep LDS addresses in range for idle lanes
+        const int rr = row_ok ? ry : 0;
+        const unsigned *rowp = reinterpret_cast<const unsigned *>(s_img + (rr + 3) * S);
+        const unsigned Dm = rowp[qq - 1], D0 = rowp[qq], Dp = rowp[qq + 1];
+        const unsigned Du = rowp[qq - 3 * (S >> 2)], Dd = rowp[qq + 3 * (S >> 2)];
+        const int cb = 4 * qq;
+        bool pass[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int v = (int)((D0 >> (8 * t)) & 0xFFu);
+            const int p12 = t == 3 ? (int)(D0 & 0xFFu) : (int)((Dm >> (8 * (t + 1))) & 0xFFu);
+            const int p4 = t == 0 ? (int)(D0 >> 24) : (int)((Dp >> (8 * (t - 1))) & 0xFFu);
+            const int p0 = (int)((Dd >> (8 * t)) & 0xFFu), p8 = (int)((Du >> (8 * t)) & 0xFFu);
+            const int vmt = v - threshold;
+            const bool rej = (NEAR(p4, vmt, th2) && NEAR(p12, vmt, th2)) || (NEAR(p0, vmt, th2) && NEAR(p8, vmt, th2));
+            bool ok = row_ok && (unsigned)(cb + t - c_lo) < c_span && !rej;
+            if (mask && ok) ok = mask[(size_t)y * lv.pitch + xs + cb + t] != 0;
+            pass[t] = ok;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const unsigned long long bal = __ballot(pass[t]);
+            if (pass[t]) my_list[n_mine + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((ry << 8) | (cb + t - c0));
+            n_mine += __popcll(bal);
         }
     }
+    if (lane == 0) s_count[wave] = n_mine;
     __syncthreads();
-    const int n_surv = *s_count;
+    const int n0 = s_count[0], n1 = n0 + s_count[1], n2 = n1 + s_count[2], n_surv = n2 + s_count[3];
+    if (g.dbg_stop == 2) return;
+    const int lx_off = c0;
+    // survivor i of the workgroup -> entry of one of the four per-wave lists
+#define SURVIVOR(i) s_list[(i) < n0 ? (i) : (i) < n1 ? L.list_cap + (i) - n0 : (i) < n2 ? 2 * L.list_cap + (i) - n1 : 3 * L.list_cap + (i) - n2]
 
     // ---- phase 2: full 16-ring test + score for the survivors ----
-    const int S = L.img_stride;
     for (int i = tid; i < n_surv; i += 256) {
-        const int e = s_list[i], ry = e >> 8, rx = e & 255;
+        const int e = SURVIVOR(i), ry = e >> 8, rx = e & 255;
         const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
         const int v = c[0], vt = v + threshold, v_t = v - threshold;
         int p[16];
@@ -174,11 +204,12 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         if (hit) s_score[ry * L.score_w + rx] = (unsigned short)sad;
     }
     __syncthreads();
+    if (g.dbg_stop == 3) return;
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key ----
     const int SW = L.score_w;
     for (int i = tid; i < n_surv; i += 256) {
-        const int e = s_list[i], ry = e >> 8, rx = e & 255;
+        const int e = SURVIVOR(i), ry = e >> 8, rx = e & 255;
         if (ry < 1 || ry > th || rx < 1 || rx > ktw) continue;        // halo entries only serve as neighbours
         const unsigned short *q = s_score + ry * SW + rx;
         const int s = q[0];
@@ -192,6 +223,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
     }
     __syncthreads();
+    if (g.dbg_stop == 4) return;
 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
     const bool active = tid < ktw && (xg0 + tid) < W;
