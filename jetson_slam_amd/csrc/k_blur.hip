@@ -4,7 +4,7 @@
 // [20,H-20) x [20,W-20): acc = 0; 49 chained single-rounding FMAs acc = fma(w[k], (float)I, acc) in raster order;
 // out = trunc(acc).  Pixels outside the ROI are never written and read as 0 (the blurred
 // slab is zero-filled once at create).  The weights are the hard-coded table of Appendix A.2.
-// MI355X design: a 256-thread workgroup stages a (32+6) x (64+12) byte tile in LDS with aligned dword loads; each
+// MI355X design: a 256-thread workgroup stages a (32+6) x 80 byte tile in LDS with 190 16-byte loads; each
 // thread produces an 8-pixel strip, reading every tile row as two ds_read_b64 and converting each byte once per
 // row (14 v_cvt_f32_ubyte instead of 56); the 8 independent FMA chains interleave freely while each chain keeps
 // the reference order.
@@ -42,12 +42,13 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
     int pitch;
     const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
 
-    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_STRIDE / 4); i += 256) {
-        const int ly = i / (BLUR_STRIDE / 4), dx = i - ly * (BLUR_STRIDE / 4);
-        const int y = y0 - 3 + ly, x = x0 - 4 + 4 * dx;
-        unsigned v = 0;
-        if (y < H && x + 4 <= pitch) v = *reinterpret_cast<const unsigned *>(img + (size_t)y * pitch + x);
-        reinterpret_cast<unsigned *>(tile)[i] = v;
+    // 16-byte staging loads (x0 - 4 is a multiple of 16: x0 = 20 + 64*bx); a tile row is 5 x 16 B
+    if (tid < (BLUR_TH + 6) * (BLUR_STRIDE / 16)) {
+        const int ly = tid / (BLUR_STRIDE / 16), dx = tid - ly * (BLUR_STRIDE / 16);
+        const int y = y0 - 3 + ly, x = x0 - 4 + 16 * dx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y < H && x + 16 <= pitch) v = *reinterpret_cast<const uint4 *>(img + (size_t)y * pitch + x);
+        reinterpret_cast<uint4 *>(tile)[tid] = v;
     }
     __syncthreads();
 
