@@ -17,13 +17,18 @@
 //   * phase 1 (all pixels): the two early rejects, branch-free, 4 pixels per lane from 5 aligned LDS dwords.  Survivors
 //     (~18 % on the benchmark images) are compacted into per-wave LDS work lists with wave64 __ballot + popcount
 //     prefixes (no atomics), so phase 2 runs on dense waves.
-//   * phase 2 (survivors): 16-pixel ring, LUT bit test (8 KB bit table, L1/L2 resident), SAD score -> LDS.
-//   * phase 3 (survivors with score > 0): 3x3 NMS from LDS and one ds_max_u32 per column with the key
-//     (score << 16 | 0xFFFF - rank), rank = ty * mini_tile + k : the max key IS the reference's column winner.
+//   * phase 2 (survivors, each wave on its own list, no barrier in between): 16-pixel ring, LUT bit test (8 KB bit table,
+//     L1/L2 resident), SAD score (v_sad_u8) -> LDS; pixels with a positive score are re-compacted in place.
+//   * phase 3 (positive scores only): 3x3 NMS from LDS and one ds_max_u32 per column with the key
+//     (score << 16 | 0xFFFF - rank), rank = ty * 256 + k : the max key IS the reference's column winner.
 //   * phase 4: the reference's horizontal tree replayed literally on <= 128 column slots in LDS.
 #include "jsorb_launch.h"
 
 namespace jsorb {
+
+// LDS image row stride (bytes).  A tile group is at most 128 px wide; + 4 px halo each side + <= 15 alignment bytes <= 151.
+// A compile-time stride turns the 16 ring offsets of phase 2 into immediate LDS offsets.
+#define DET_S 160
 
 struct DetectLds {
     int img_stride;      // bytes per LDS image row (multiple of 16)
@@ -31,14 +36,14 @@ struct DetectLds {
     int score_w;         // k*tw + 2
     int score_rows;      // th + 2
     int list_cap;        // survivor-list capacity of ONE wave (entries)
-    size_t off_score, off_list, off_colkey, off_tree, off_count, total;
+    size_t off_score, off_list, off_colkey, off_tree, total;
 };
 
 __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_tiles)
 {
     DetectLds d;
     const int ktw = k_tiles * tw;
-    d.img_stride = ((ktw + 8 + 15 + 15) & ~15);    // window is 16-byte aligned on the left: up to 15 extra bytes
+    d.img_stride = DET_S;                          // fixed: window is 16-byte aligned on the left (<= 15 extra bytes), ktw <= 128
     d.img_rows = th + 8;
     d.score_w = ktw + 2;
     d.score_rows = th + 2;
@@ -55,8 +60,6 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     o += 128 * 4;
     d.off_tree = o;
     o += 128 * 8;
-    d.off_count = o;
-    o += 32;
     d.total = o;
     return d;
 }
@@ -74,6 +77,7 @@ size_t detect_lds_bytes(const Geometry &g)
 // |a - v| <= th  <=>  (unsigned)(a - (v - th)) <= 2*th
 #define NEAR(a, vmt, th2) ((unsigned)((a) - (vmt)) <= (th2))
 
+template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out)
 {
@@ -98,7 +102,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
     unsigned *s_colkey = reinterpret_cast<unsigned *>(smem + L.off_colkey);
     unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
-    int *s_count = reinterpret_cast<int *>(smem + L.off_count);     // [4] survivors per wave
 
     int pitch;
     const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // ---- phase 0: stage image rows [y0-4, y0+th+4) x cols [xs, xs+S) with 16-byte loads ; zero the score tile ----
     // (4-byte loads cap a CU at ~1/4 of its HBM rate: the vector-memory pipeline retires one wave-instruction per
     //  ~16 clk whatever its width, so staging uses global_load_dwordx4 / ds_write_b128 throughout)
-    const int S = L.img_stride;
+    constexpr int S = DET_S;
     const int xs = (xg0 - 4) & ~15;                       // 16-byte aligned (may be negative)
-    const int nq16 = S >> 4;
+    constexpr int nq16 = S >> 4;
     for (int i = tid; i < L.img_rows * nq16; i += 256) {
         const int ly = i / nq16, dx = i - ly * nq16;
         const int y = y0 - 4 + ly, x = xs + 16 * dx;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     const int nq = ((c0 + L.score_w - 1) >> 2) - q0 + 1;  // dwords per region row
     const int c_lo = max(c0, JSORB_BORDER - xs), c_hi = min(c0 + L.score_w, W - JSORB_BORDER - xs);
     const unsigned c_span = c_hi > c_lo ? (unsigned)(c_hi - c_lo) : 0u;
-    const uint8_t *mask = g.has_mask ? mask_slab + lv.img_off : nullptr;
+    const uint8_t *mask = HAS_MASK ? mask_slab + lv.img_off : nullptr;
     const int two_rows = nq <= 32 ? 1 : 0;
     const int sub = two_rows ? (lane >> 5) : 0;
     const int q = two_rows ? (lane & 31) : lane;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             const int vmt = v - threshold;
             const bool rej = (NEAR(p4, vmt, th2) && NEAR(p12, vmt, th2)) || (NEAR(p0, vmt, th2) && NEAR(p8, vmt, th2));
             bool ok = row_ok && (unsigned)(cb + t - c_lo) < c_span && !rej;
-            if (mask && ok) ok = mask[(size_t)y * lv.pitch + xs + cb + t] != 0;
+            if (HAS_MASK) { if (ok) ok = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
             pass[t] = ok;
         }
 #pragma unroll
@@ -173,59 +176,105 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             n_mine += __popcll(bal);
         }
     }
-    if (lane == 0) s_count[wave] = n_mine;
-    __syncthreads();
-    const int n0 = s_count[0], n1 = n0 + s_count[1], n2 = n1 + s_count[2], n_surv = n2 + s_count[3];
     if (g.dbg_stop == 2) return;
-    const int lx_off = c0;
-    // survivor i of the workgroup -> entry of one of the four per-wave lists
-#define SURVIVOR(i) s_list[(i) < n0 ? (i) : (i) < n1 ? L.list_cap + (i) - n0 : (i) < n2 ? 2 * L.list_cap + (i) - n1 : 3 * L.list_cap + (i) - n2]
 
-    // ---- phase 2: full 16-ring test + score for the survivors ----
-    for (int i = tid; i < n_surv; i += 256) {
-        const int e = SURVIVOR(i), ry = e >> 8, rx = e & 255;
-        const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
-        const int v = c[0], vt = v + threshold, v_t = v - threshold;
-        int p[16];
-        p[0] = c[3 * S];       p[1] = c[3 * S + 1];   p[2] = c[2 * S + 2];   p[3] = c[S + 3];
-        p[4] = c[3];           p[5] = c[-S + 3];      p[6] = c[-2 * S + 2];  p[7] = c[-3 * S + 1];
-        p[8] = c[-3 * S];      p[9] = c[-3 * S - 1];  p[10] = c[-2 * S - 2]; p[11] = c[-S - 3];
-        p[12] = c[-3];         p[13] = c[S - 3];      p[14] = c[2 * S - 2];  p[15] = c[3 * S - 1];
-        unsigned bright = 0, dark = 0;
-        int sad = 0;
+    // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
+    // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
+    // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
+    const int lx_off = c0;
+    int n_pos = 0;                                        // wave-uniform
+    for (int i0 = 0; i0 < n_mine; i0 += 64) {
+        const int i = i0 + lane;
+        bool hit = false;
+        int e = 0;
+        if (i < n_mine) {
+            e = my_list[i];
+            const int ry = e >> 8, rx = e & 255;
+            const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
+            const int v = c[0], vt = v + threshold, v_t = v - threshold;
+            int p[16];
+            p[0] = c[3 * S];       p[1] = c[3 * S + 1];   p[2] = c[2 * S + 2];   p[3] = c[S + 3];
+            p[4] = c[3];           p[5] = c[-S + 3];      p[6] = c[-2 * S + 2];  p[7] = c[-3 * S + 1];
+            p[8] = c[-3 * S];      p[9] = c[-3 * S - 1];  p[10] = c[-2 * S - 2]; p[11] = c[-S - 3];
+            p[12] = c[-3];         p[13] = c[S - 3];      p[14] = c[2 * S - 2];  p[15] = c[3 * S - 1];
+            // brighter / darker masks, bit k = ring pixel k.  Two VALU per bit and no SGPR round trip: the sign bit of
+            // (vt - p) [p > vt] or (p - v_t) [p < v_t] is shifted into the mask with one v_alignbit_b32.
+            unsigned bright = 0, dark = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            bright |= (unsigned)(p[k] > vt) << k;
-            dark |= (unsigned)(p[k] < v_t) << k;
-            const int d = p[k] - v;
-            sad += d < 0 ? -d : d;
+            for (int k = 15; k >= 0; k--) {
+                bright = __builtin_amdgcn_alignbit(bright, (unsigned)(vt - p[k]), 31);
+                dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p[k] - v_t), 31);
+            }
+            hit = (((lut_bits[bright >> 5] >> (bright & 31)) | (lut_bits[dark >> 5] >> (dark & 31))) & 1u) != 0;
+            if (hit) {
+                const unsigned v4 = (unsigned)v * 0x01010101u;
+                unsigned sad = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 4)
+                    sad = __builtin_amdgcn_sad_u8((unsigned)p[k] | ((unsigned)p[k + 1] << 8) | ((unsigned)p[k + 2] << 16) | ((unsigned)p[k + 3] << 24), v4, sad);
+                s_score[ry * L.score_w + rx] = (unsigned short)sad;
+            }
         }
-        const unsigned hit = ((lut_bits[bright >> 5] >> (bright & 31)) | (lut_bits[dark >> 5] >> (dark & 31))) & 1u;
-        if (hit) s_score[ry * L.score_w + rx] = (unsigned short)sad;
+        const unsigned long long bal = __ballot(hit);
+        if (hit) my_list[n_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+        n_pos += __popcll(bal);
     }
     __syncthreads();
     if (g.dbg_stop == 3) return;
 
-    // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key ----
+    // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key, positives of the wave's own list ----
     const int SW = L.score_w;
-    for (int i = tid; i < n_surv; i += 256) {
-        const int e = SURVIVOR(i), ry = e >> 8, rx = e & 255;
+    const int n_ty = lv.n_ty, recip_nty = (65536 + n_ty - 1) / n_ty;
+    for (int i = lane; i < n_pos; i += 64) {
+        const int e = my_list[i], ry = e >> 8, rx = e & 255;
         if (ry < 1 || ry > th || rx < 1 || rx > ktw) continue;        // halo entries only serve as neighbours
         const unsigned short *q = s_score + ry * SW + rx;
         const int s = q[0];
-        if (s == 0) continue;
         const bool valid = s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
                            s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];
         if (!valid) continue;
         const int dy = ry - 1;
-        const int kk = dy / lv.n_ty, ty = dy - kk * lv.n_ty;
-        const unsigned rank = (unsigned)(ty * lv.mini_tile + kk);
+        const int kk = (dy * recip_nty) >> 16, ty = dy - kk * n_ty;      // dy / n_ty, exact for dy < 8192 (n_ty <= 8)
+        const unsigned rank = (unsigned)(ty * 256 + kk);                 // lexicographic (ty, k); k < mini_tile <= 128
         atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
     }
     __syncthreads();
     if (g.dbg_stop == 4) return;
 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
+    // A slot of the reference's shared array always equals the current register value of its owner thread at a round
+    // boundary, so for tiles that fit one wave the tree is replayed with wave shuffles (no LDS traffic, no barriers):
+    // wave w owns tiles w, w+4, ... of the group, lane j is column j of the tile.
+    if (tw <= 64) {
+        for (int tile = wave; tile < lv.k_tiles; tile += 4) {
+            const int col = tile * tw + lane;
+            const bool in_tile = lane < tw;
+            const bool active = in_tile && (xg0 + col) < W;
+            int sc = 0, yy = y0;
+            if (in_tile) {
+                const unsigned key = s_colkey[col];
+                sc = (int)(key >> 16);
+                if (sc > 0) {
+                    const int rank = (int)(0xFFFFu - (key & 0xFFFFu));
+                    yy = y0 + (rank >> 8) + (rank & 255) * lv.n_ty;
+                }
+            }
+            unsigned cur_lo = ((unsigned)(yy & 0xFFFF) << 16) | (unsigned)((xg0 + col) & 0xFFFF);   // pack_kp layout
+            int cur_sc = sc;
+            int gs = (tw - 1) / 2 + 1;
+            for (int it = 0; it < lv.log2_tw; it++) {
+                const int o_sc = __shfl_down(cur_sc, gs, 64);
+                const unsigned o_lo = (unsigned)__shfl_down((int)cur_lo, gs, 64);
+                if (active && lane < gs && lane + gs < tw && cur_sc < o_sc) { cur_sc = o_sc; cur_lo = o_lo; }
+                gs = (gs - 1) / 2 + 1;
+            }
+            if (active && lane == 0) {
+                const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tile;
+                tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] = ((unsigned long long)(unsigned)cur_sc << 32) | cur_lo;
+            }
+        }
+        return;
+    }
     const bool active = tid < ktw && (xg0 + tid) < W;
     int tile_in_grp = 0, tile_loc = 0;
     unsigned long long cur = 0;
@@ -238,8 +287,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             sc = (int)(key >> 16);
             if (sc > 0) {
                 const int rank = (int)(0xFFFFu - (key & 0xFFFFu));
-                const int ty = rank / lv.mini_tile, kk = rank - ty * lv.mini_tile;
-                yy = y0 + ty + kk * lv.n_ty;
+                yy = y0 + (rank >> 8) + (rank & 255) * lv.n_ty;
             }
         }
         cur = pack_kp(sc, 0, yy, xg0 + tid);
@@ -267,7 +315,10 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_detect, dim3(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out);
+    if (g.has_mask)
+        hipLaunchKernelGGL(k_detect<true>, dim3(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out);
+    else
+        hipLaunchKernelGGL(k_detect<false>, dim3(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out);
 }
 
 } // namespace jsorb
