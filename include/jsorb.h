@@ -31,7 +31,7 @@ extern "C" {
 #define JSORB_OK 0
 #define JSORB_ERR_INVALID (-1)      /* bad argument / unsupported parameter combination */
 #define JSORB_ERR_HIP (-2)          /* a HIP runtime call failed (see jsorb_last_error) */
-#define JSORB_ERR_UNSUPPORTED (-3)  /* feature of the reference not built yet (NMS-MS) */
+#define JSORB_ERR_UNSUPPORTED (-3)  /* parameter combination outside what this build supports */
 #define JSORB_ERR_STATE (-4)        /* call order violation (e.g. stereo before extract) */
 
 #define JSORB_MAX_LEVELS 16
@@ -61,7 +61,7 @@ typedef struct jsorb_stereo_stats {
 } jsorb_stereo_stats;
 
 /* kernel ids for jsorb_kernel_time */
-enum { JSORB_K_PYRAMID = 0, JSORB_K_DETECT, JSORB_K_COMPACT, JSORB_K_BLUR, JSORB_K_DESCRIBE, JSORB_K_STEREO, JSORB_K_MEDIAN, JSORB_K_COUNT };
+enum { JSORB_K_PYRAMID = 0, JSORB_K_DETECT, JSORB_K_COMPACT, JSORB_K_BLUR, JSORB_K_DESCRIBE, JSORB_K_STEREO, JSORB_K_MEDIAN, JSORB_K_NMS_MS, JSORB_K_COUNT };
 
 /* ---- lifetime ---- */
 /* mask: NULL (no mask => all 255) or a height*width u8 level-0 mask in host memory. */

@@ -24,7 +24,7 @@ using namespace jsorb;
 
 namespace {
 
-const char *k_names[JSORB_K_COUNT] = {"k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median"};
+const char *k_names[JSORB_K_COUNT] = {"k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median", "k_nms_ms"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -52,6 +52,8 @@ struct jsorb_extractor {
     float *st_u = nullptr, *st_d = nullptr;
     int *st_l1 = nullptr, *st_stats = nullptr;
     unsigned *st_aux = nullptr;
+    bool nms_ms = false;
+    int *ms_grid = nullptr, *ms_scratch = nullptr;   // NMS-MS: level-0 accumulator plane (GPU mode) / mutable scores (CPU mode)
     // pinned host mirrors
     int *h_counts = nullptr, *h_stats = nullptr;
     ImageSrc src{};            // where level 0 of the last extract lives
@@ -219,6 +221,7 @@ int run_pipeline(jsorb_extractor *e, int n)
     }
     TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, n, e->pyr_lds, e->stream));
     TIMED(e, JSORB_K_DETECT, launch_detect(g, e->src, e->slab, e->mask, e->lut_bits, e->tile_out, n, e->detect_lds, e->stream));
+    if (e->nms_ms) TIMED(e, JSORB_K_NMS_MS, launch_nms_ms(g, e->tile_out, e->ms_grid, e->ms_scratch, e->p.nms_ms_mode_gpu, n, e->stream));
     TIMED(e, JSORB_K_COMPACT, launch_compact(g, e->tile_out, e->kp, e->counts, e->row_tab, n, e->stream));
     TIMED(e, JSORB_K_BLUR, launch_blur(g, e->src, e->slab, e->blur, n, e->stream));
     TIMED(e, JSORB_K_DESCRIBE, launch_describe(g, e->src, e->slab, e->blur, e->kp, e->counts, e->angles, e->desc, e->out_kp, n, e->stream));
@@ -254,10 +257,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     e->p = *params;
     e->B = params->max_batch < 1 ? 1 : params->max_batch;
     e->device = params->device_id;
-    if (params->apply_nms_ms && params->n_levels > 1) {
-        e->err = "apply_nms_ms (multi-scale NMS / PFA, orb_FAST_apply_NMS_MS.cu) is not built yet";
-        return JSORB_ERR_UNSUPPORTED;
-    }
+    e->nms_ms = params->apply_nms_ms && params->n_levels > 1;      // auto-disabled for one level (orb_gpu.cpp:37)
     int rc = build_geometry(*params, e->g, e->err);
     if (rc) return rc;
     Geometry &g = e->g;
@@ -290,6 +290,16 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipMalloc(&e->st_d, B * T * 4));
     HIPCHK(e, hipMalloc(&e->st_l1, B * T * 4));
     HIPCHK(e, hipMalloc(&e->st_aux, B * T * 4));
+    if (e->nms_ms) {
+        if (params->nms_ms_mode_gpu) {
+            const size_t n = B * (size_t)g.lv[0].H * g.lv[0].W * sizeof(int);
+            HIPCHK(e, hipMalloc(&e->ms_grid, n));
+            HIPCHK(e, hipMemset(e->ms_grid, 0, n));
+        } else {
+            if (g.T > 32768 || g.lv[0].nth * g.lv[0].ntw > 65535) { e->err = "NMS-MS CPU mode supports at most 32768 tiles"; return JSORB_ERR_UNSUPPORTED; }
+            HIPCHK(e, hipMalloc(&e->ms_scratch, B * T * sizeof(int)));
+        }
+    }
     HIPCHK(e, hipMalloc(&e->st_stats, B * 8 * sizeof(int)));
     HIPCHK(e, hipMemset(e->counts, 0, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
     HIPCHK(e, hipHostMalloc(&e->h_counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
@@ -330,7 +340,7 @@ void jsorb_destroy(jsorb_extractor *e)
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);

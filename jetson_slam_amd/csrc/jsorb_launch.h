@@ -22,6 +22,7 @@ size_t pyramid_lds_bytes(const Geometry &g);
 void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, int n_images, size_t lds_bytes, hipStream_t s);
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);
+void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s);
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s);

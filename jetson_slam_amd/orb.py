@@ -19,7 +19,7 @@ _LIB_PATH = os.path.join(_HERE, "libjsorb.so")
 MAX_LEVELS = 16
 TH_HIGH, TH_LOW = 100, 50   # ORBmatcher::TH_HIGH / TH_LOW, src/ORBmatcher.cpp:24-25
 
-KERNELS = ["k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median"]
+KERNELS = ["k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median", "k_nms_ms"]
 
 EXPORTS = [
     "jsorb_create", "jsorb_destroy", "jsorb_last_error", "jsorb_version", "jsorb_extract", "jsorb_extract_device",

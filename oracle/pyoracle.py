@@ -62,6 +62,7 @@ def _load(native=False):
         "orc_hamming256": (C.c_int, [C.c_void_p, C.c_void_p]),
         "orc_desc_offset": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
         "orc_nms_tiles_plane": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "orc_nms_ms_gpu_candidates": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "orc_orientation_px": (C.c_float, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
         "orc_descriptor_px": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
         "orc_bench_pairs": (C.c_long, [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double,

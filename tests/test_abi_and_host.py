@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(libpath):
     lib.jsorb_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.jsorb_version()
     lib.jsorb_kernel_name.restype = ctypes.c_char_p
-    assert [lib.jsorb_kernel_name(i).decode() for i in range(7)] == orb.KERNELS
+    assert [lib.jsorb_kernel_name(i).decode() for i in range(8)] == orb.KERNELS
 
 
 def test_code_object_targets_gfx950(libpath):
