@@ -37,6 +37,18 @@ def algo_bytes_per_pair(ex):
     return 6 * P + 24 * ex.T, P, ex.T
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (cpu.max) when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(cfg, host_pairs, budget_s=12.0):
     """The oracle (kind 'port': the reference has no CPU path), OpenMP over independent pairs on all host
     cores, built -O3 -march=native on this box, same workload, bounded to ~budget_s of wall time."""
@@ -47,7 +59,7 @@ def cpu_baseline(cfg, host_pairs, budget_s=12.0):
         native = True
     except Exception:
         native = False
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     lefts = np.stack([p[0] for p in host_pairs])
     rights = np.stack([p[1] for p in host_pairs])
     kw = dict(height=H, width=W, n_levels=L, tile_h=tile, tile_w=tile, th_fast_max=th)
@@ -64,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per GPU per step")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
@@ -160,6 +172,12 @@ def main():
                       and np.array_equal(u.view(np.uint32), ou.view(np.uint32)) and np.array_equal(d.view(np.uint32), od.view(np.uint32)))
 
     # ---- per-kernel hipEvent timing pass (serialises launches, so it is separate from the timed region) ----
+    # both handles on ONE stream here, so that a kernel's event-to-event time is its own duration and not the overlap with the
+    # other handle's kernels (the timed region above overlaps left and right on two streams)
+    if shared_stream is None:
+        shared_stream = torch.cuda.Stream(dev)
+        exl.set_stream(shared_stream.cuda_stream)
+        exr.set_stream(shared_stream.cuda_stream)
     for e in (exl, exr):
         e.reset_kernel_timing()
         e.enable_kernel_timing(True)

@@ -24,12 +24,12 @@ __device__ __forceinline__ constexpr unsigned gauss_bits(int d)
 #define BLUR_TH 32
 #define BLUR_STRIDE 80
 
-__global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab)
+__global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, int n_images)
 {
     __shared__ __align__(16) unsigned char tile[(BLUR_TH + 6) * BLUR_STRIDE];
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int blk = blockIdx.x;
+    int b, blk;
+    if (!xcd_map(blockIdx.x, g.blur_blocks, n_images, b, blk)) return;
     int lvl = 0;
 #pragma unroll 1
     for (int i = 1; i < g.L; i++)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s)
 {
     if (g.blur_blocks == 0) return;
-    hipLaunchKernelGGL(k_blur, dim3(g.blur_blocks, n_images), dim3(256), 0, s, g, src, slab, blur_slab);
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(g.blur_blocks, n_images)), dim3(256), 0, s, g, src, slab, blur_slab, n_images);
 }
 
 } // namespace jsorb

@@ -79,12 +79,12 @@ size_t detect_lds_bytes(const Geometry &g)
 
 template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out)
+                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int blk = blockIdx.x;
+    int b, blk;
+    if (!xcd_map(blockIdx.x, g.detect_blocks, n_images, b, blk)) return;
     int lvl = 0;
 #pragma unroll 1
     for (int i = 1; i < g.L; i++)
@@ -316,9 +316,9 @@ void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, 
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
     if (g.has_mask)
-        hipLaunchKernelGGL(k_detect<true>, dim3(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out);
+        hipLaunchKernelGGL(k_detect<true>, dim3(xcd_grid(g.detect_blocks, n_images)), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images);
     else
-        hipLaunchKernelGGL(k_detect<false>, dim3(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out);
+        hipLaunchKernelGGL(k_detect<false>, dim3(xcd_grid(g.detect_blocks, n_images)), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images);
 }
 
 } // namespace jsorb

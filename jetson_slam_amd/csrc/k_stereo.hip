@@ -37,14 +37,14 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
                                                const int *__restrict__ row_tabR,
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
-                                               unsigned *__restrict__ aux, StereoArgs sa)
+                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs)
 {
     __shared__ unsigned s_left[11 * 4];
     __shared__ unsigned s_right[11 * 8];
     __shared__ int s_acc[12];
     const int lane = threadIdx.x;
-    const int b = blockIdx.y;
-    const int i = blockIdx.x;
+    int b, i;
+    if (!xcd_map(blockIdx.x, g.T, n_pairs, b, i)) return;
     const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     const int Nr = countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     if (i >= Nl) return;
@@ -298,8 +298,8 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
                    float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_stereo, dim3(g.T, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
-                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a);
+    hipLaunchKernelGGL(k_stereo, dim3(xcd_grid(g.T, n_pairs)), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
+                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs);
 }
 
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,

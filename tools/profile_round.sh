@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): bench line + rocprofv3 kernel-trace stats + HBM traffic counters for one round.
+# Usage: tools/profile_round.sh r01   -> gpurun_out/<tag>_*  (copy the summaries you want judged into profiles/)
+# --pmc passes are separate runs and never combined with trace domains other than the kernel trace.
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$ROOT/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $ROOT/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+B="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-steps 0 --single-stream"   # one stream: per-kernel durations are not inflated by left/right overlap
+rm -rf $O/${TAG}_trace $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_sq
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o t -- $B > $O/${TAG}_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o p -- $B > $O/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_write -o p -- $B > $O/${TAG}_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/${TAG}_sq -o p -- $B > $O/${TAG}_sq.log 2>&1
+python $ROOT/tools/profile_summary.py $TAG
