@@ -45,12 +45,12 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
     const int lane = threadIdx.x;
     int b, i;
     if (!xcd_map(blockIdx.x, g.T, n_pairs, b, i)) return;
-    const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
-    const int Nr = countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
+    const int Nl = uniform_i32(countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
+    const int Nr = uniform_i32(countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
     if (i >= Nl) return;
     const int32_t *oL = outL + (size_t)b * 6 * g.T;
     const int32_t *oR = outR + (size_t)b * 6 * g.T;
-    const int xL0 = oL[i], yL0 = oL[Nl + i], levelL = oL[4 * (size_t)Nl + i];
+    const int xL0 = uniform_i32(oL[i]), yL0 = uniform_i32(oL[Nl + i]), levelL = uniform_i32(oL[4 * (size_t)Nl + i]);
     const float uL = (float)xL0, vL = (float)yL0;
     const float minU = uL - sa.maxD, maxU = uL - 0.0f;
     const size_t tb = (size_t)b * g.T;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                 int t_hi = hi < 0 ? -1 : hi / lv.th;
                 if (t_hi > lv.nth - 1) t_hi = lv.nth - 1;
                 if (t_lo <= t_hi) {
-                    j0[t] = rt[lv.row_tab_off + t_lo];
-                    len[t] = rt[lv.row_tab_off + t_hi + 1] - j0[t];
+                    j0[t] = uniform_i32(rt[lv.row_tab_off + t_lo]);
+                    len[t] = uniform_i32(rt[lv.row_tab_off + t_hi + 1]) - j0[t];
                 }
             }
         }
@@ -104,15 +104,15 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             }
         }
     }
-    best_key = wave_min_u32(best_key);
-    n_cand = wave_sum_i32(n_cand);
+    best_key = (unsigned)uniform_i32((int)wave_min_u32(best_key));
+    n_cand = uniform_i32(wave_sum_i32(n_cand));
 
     float out_u = -1.0f, out_d = -1.0f;
     int out_l1 = -1, corr = 0;
     if (best_key != 0xFFFFFFFFu && (int)(best_key >> 20) < sa.th_orb) {     // workgroup-uniform
         const int bestIdxR = (int)(best_key & 0xFFFFFu);
         const LevelDesc &lv = g.lv[levelL];
-        const float uR0 = (float)oR[bestIdxR];
+        const float uR0 = (float)uniform_i32(oR[bestIdxR]);
         const float scaleFactor = lv.inv_scale;
         const float scaleduR0 = roundf(uR0 * scaleFactor);
         const float scaleduL0 = roundf(uL * scaleFactor);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             __syncthreads();
             int acc[11];
 #pragma unroll
-            for (int s = 0; s < 11; s++) acc[s] = s_acc[s];
+            for (int s = 0; s < 11; s++) acc[s] = uniform_i32(s_acc[s]);
             int bestDist = 0x7FFFFFFF, bestR = 0;
 #pragma unroll
             for (int s = 0; s < 11; s++)
