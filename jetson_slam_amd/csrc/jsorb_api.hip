@@ -43,6 +43,7 @@ struct jsorb_extractor {
     size_t detect_lds = 0, pyr_lds = 0;
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
+    uint8_t *stage = nullptr;  // dense B x H0 x W0 landing buffer for host uploads (one hipMemcpyAsync per batch, then read in place)
     uint32_t *lut_bits = nullptr;
     unsigned long long *tile_out = nullptr, *kp = nullptr;
     int *counts = nullptr, *row_tab = nullptr;
@@ -278,6 +279,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipMalloc(&e->blur, slab_total));
     HIPCHK(e, hipMemset(e->slab, 0, slab_total));
     HIPCHK(e, hipMemset(e->blur, 0, slab_total));   // blurred image is 0 outside the ROI (Appendix C-2)
+    if (g.lv[0].W % 16 == 0) HIPCHK(e, hipMalloc(&e->stage, B * (size_t)g.lv[0].H * g.lv[0].W + 256));
     HIPCHK(e, hipMalloc(&e->lut_bits, 2048 * sizeof(uint32_t)));
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
@@ -339,7 +341,7 @@ void jsorb_destroy(jsorb_extractor *e)
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    void *bufs[] = {e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
+    void *bufs[] = {e->stage, e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
                     e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -380,10 +382,17 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     if (!e || !host_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
-    for (int i = 0; i < n_images; i++)   // pinned hipMemcpyAsync path of the north star (one 2-D copy per image)
-        HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
-                                   l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
-    e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
+    const size_t img_bytes = (size_t)l0.H * l0.W;
+    if (e->stage && step == l0.W && (n_images == 1 || image_stride == img_bytes)) {
+        // dense batch: ONE pinned hipMemcpyAsync for all images, then level 0 is read in place from the landing buffer
+        HIPCHK(e, hipMemcpyAsync(e->stage, host_images, img_bytes * n_images, hipMemcpyHostToDevice, e->stream));
+        e->src.l0 = e->stage; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
+    } else {
+        for (int i = 0; i < n_images; i++)   // strided input: one 2-D copy per image into the pitched slab
+            HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
+                                       l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
+        e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
+    }
     return run_pipeline(e, n_images);
 }
 
