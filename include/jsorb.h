@@ -122,6 +122,22 @@ int jsorb_copy_stereo(const jsorb_extractor *left, int image, float *u_right, fl
  * buffer (enqueued on left's stream) - the payload of the one collective of this path, an all-gather of per-pair counts. */
 int jsorb_gather_counts_async(jsorb_extractor *left, jsorb_extractor *right, int32_t *dev_dst);
 
+/* ---- Tracking-side GPU helpers: device pointers in and out, synchronous like the reference ---- */
+/* orb_cuda::ORB_Search_by_projection_project_on_frame  include/cuda/orb_matcher.hpp:12-18, src/cuda/orb_matcher.cu:17-89 */
+int jsorb_project_points(void *hip_stream, int n_points, const float *Px, const float *Py, const float *Pz, const float *Rcw, const float *tcw,
+                         float fx, float fy, float cx, float cy, float minX, float maxX, float minY, float maxY,
+                         float *u, float *v, float *invz, unsigned char *is_valid);
+/* orb_cuda::ORB_compute_distances  include/cuda/orb_matcher.hpp:20-24, src/cuda/orb_matcher.cu:95-144 (descriptor bases 16-byte aligned) */
+int jsorb_hamming_pairs(void *hip_stream, int n_pairs, const int *idx_left, const int *idx_right, const unsigned char *descriptor_left,
+                        const unsigned char *descriptor_right, int *distance);
+/* tracking_cuda::compute_isInFrustum_GPU  include/cuda/tracking_gpu.hpp, src/cuda/tracking_isinfrustum.cu:19-160
+ * (u, v, invz, predictedlevel, viewCos are written only where is_infrustum becomes 1, as in the reference) */
+int jsorb_is_in_frustum(void *hip_stream, int n_points, const float *Px, const float *Py, const float *Pz, const float *Pnx, const float *Pny,
+                        const float *Pnz, const float *MaxDistance, const float *invariance_maxDistance, const float *invariance_minDistance,
+                        const float *Rcw, const float *tcw, const float *Ow, float fx, float fy, float cx, float cy, int minX, int maxX, int minY,
+                        int maxY, int nScaleLevels, float logScaleFactor, float viewCosAngle, float *invz, float *u, float *v, int *predictedlevel,
+                        float *viewCos, unsigned char *is_infrustum);
+
 /* ---- plumbing ---- */
 /* Use an external HIP stream (hipStream_t as void*) instead of the handle's own, e.g. torch's current stream. NULL restores. */
 int jsorb_set_stream(jsorb_extractor *e, void *hip_stream);

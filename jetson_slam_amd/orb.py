@@ -29,7 +29,7 @@ EXPORTS = [
     "jsorb_inv_scale", "jsorb_level_image_device", "jsorb_copy_level_image", "jsorb_copy_tile_candidates", "jsorb_copy_angles",
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
     "jsorb_copy_stereo", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
-    "jsorb_reset_kernel_timing", "jsorb_kernel_name",
+    "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
 ]
 
 
@@ -102,6 +102,9 @@ def load_library(path=None):
         "jsorb_kernel_time": (I, [P, I, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
         "jsorb_reset_kernel_timing": (I, [P]),
         "jsorb_kernel_name": (C.c_char_p, [I]),
+        "jsorb_project_points": (I, [P, I] + [P] * 5 + [F] * 8 + [P] * 4),
+        "jsorb_hamming_pairs": (I, [P, I] + [P] * 5),
+        "jsorb_is_in_frustum": (I, [P, I] + [P] * 12 + [F] * 4 + [I] * 5 + [F] * 2 + [P] * 6),
     }
     for name, (rt, at) in sig.items():
         fn = getattr(lib, name)

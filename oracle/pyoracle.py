@@ -65,6 +65,10 @@ def _load(native=False):
         "orc_nms_ms_gpu_candidates": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "orc_orientation_px": (C.c_float, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
         "orc_descriptor_px": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+        "orc_project_points": (None, [C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 8 + [C.c_void_p] * 4),
+        "orc_hamming_pairs": (None, [C.c_int] + [C.c_void_p] * 5),
+        "orc_logf": (C.c_float, [C.c_float]),
+        "orc_is_in_frustum": (None, [C.c_int] + [C.c_void_p] * 12 + [C.c_float] * 4 + [C.c_int] * 5 + [C.c_float] * 2 + [C.c_void_p] * 6),
         "orc_bench_pairs": (C.c_long, [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double,
                                       C.c_int, C.POINTER(C.c_double)]),
         "orc_stereo_match": (C.c_int, [P, P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
