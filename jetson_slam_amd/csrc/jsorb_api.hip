@@ -43,7 +43,13 @@ struct jsorb_extractor {
     size_t detect_lds = 0, pyr_lds = 0;
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
-    uint8_t *stage = nullptr;  // dense B x H0 x W0 landing buffer for host uploads (one hipMemcpyAsync per batch, then read in place)
+    // host uploads: two dense B x H0 x W0 landing buffers filled by ONE hipMemcpyAsync per batch on a dedicated copy stream, then read
+    // in place as level 0.  Double buffering lets the upload of batch k+1 overlap the kernels of batch k.
+    uint8_t *stage[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    bool consumed_valid[2] = {false, false};
+    int stage_cur = 0, last_stage = -1;
     uint32_t *lut_bits = nullptr;
     unsigned long long *tile_out = nullptr, *kp = nullptr;
     int *counts = nullptr, *row_tab = nullptr;
@@ -279,7 +285,14 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipMalloc(&e->blur, slab_total));
     HIPCHK(e, hipMemset(e->slab, 0, slab_total));
     HIPCHK(e, hipMemset(e->blur, 0, slab_total));   // blurred image is 0 outside the ROI (Appendix C-2)
-    if (g.lv[0].W % 16 == 0) HIPCHK(e, hipMalloc(&e->stage, B * (size_t)g.lv[0].H * g.lv[0].W + 256));
+    if (g.lv[0].W % 16 == 0) {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(e, hipMalloc(&e->stage[k], B * (size_t)g.lv[0].H * g.lv[0].W + 256));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_copied[k], hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k], hipEventDisableTiming));
+        }
+    }
     HIPCHK(e, hipMalloc(&e->lut_bits, 2048 * sizeof(uint32_t)));
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
@@ -341,7 +354,7 @@ void jsorb_destroy(jsorb_extractor *e)
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    void *bufs[] = {e->stage, e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
+    void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
                     e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -349,6 +362,11 @@ void jsorb_destroy(jsorb_extractor *e)
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->done) (void)hipEventDestroy(e->done);
     if (e->readers_done) (void)hipEventDestroy(e->readers_done);
+    for (int k = 0; k < 2; k++) {
+        if (e->ev_copied[k]) (void)hipEventDestroy(e->ev_copied[k]);
+        if (e->ev_consumed[k]) (void)hipEventDestroy(e->ev_consumed[k]);
+    }
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -383,16 +401,42 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
     const size_t img_bytes = (size_t)l0.H * l0.W;
-    if (e->stage && step == l0.W && (n_images == 1 || image_stride == img_bytes)) {
-        // dense batch: ONE pinned hipMemcpyAsync for all images, then level 0 is read in place from the landing buffer
-        HIPCHK(e, hipMemcpyAsync(e->stage, host_images, img_bytes * n_images, hipMemcpyHostToDevice, e->stream));
-        e->src.l0 = e->stage; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
+    if (e->stage[0] && step == l0.W && n_images == 1) {
+        // single frame (the reference-shaped call): lowest latency - upload on the compute stream itself, no cross-stream hops
+        if (e->has_readers) {   // the previous stereo match (enqueued on the other handle's stream) read this buffer in place
+            HIPCHK(e, hipStreamWaitEvent(e->stream, e->readers_done, 0));
+            e->has_readers = false;
+        }
+        HIPCHK(e, hipMemcpyAsync(e->stage[0], host_images, img_bytes, hipMemcpyHostToDevice, e->stream));
+        e->src.l0 = e->stage[0]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
+        e->last_stage = -1;
+        e->consumed_valid[0] = false;
+        e->stage_cur = 1;       // a following batch call starts on the other buffer
+        return run_pipeline(e, n_images);
+    }
+    if (e->stage[0] && step == l0.W && image_stride == img_bytes) {
+        // dense batch: ONE pinned hipMemcpyAsync for all images on the copy stream, then level 0 is read in place from the landing
+        // buffer.  The buffer being refilled was last read two batches ago (its extract kernels and, if any, the stereo match).
+        const int k = e->stage_cur;
+        if (e->consumed_valid[k]) HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->ev_consumed[k], 0));
+        HIPCHK(e, hipMemcpyAsync(e->stage[k], host_images, img_bytes * n_images, hipMemcpyHostToDevice, e->copy_stream));
+        HIPCHK(e, hipEventRecord(e->ev_copied[k], e->copy_stream));
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_copied[k], 0));
+        e->src.l0 = e->stage[k]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
+        const int rc = run_pipeline(e, n_images);
+        if (rc) return rc;
+        HIPCHK(e, hipEventRecord(e->ev_consumed[k], e->stream));
+        e->consumed_valid[k] = true;
+        e->last_stage = k;
+        e->stage_cur = k ^ 1;
+        return JSORB_OK;
     } else {
         for (int i = 0; i < n_images; i++)   // strided input: one 2-D copy per image into the pitched slab
             HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
                                        l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
         e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
     }
+    e->last_stage = -1;
     return run_pipeline(e, n_images);
 }
 
@@ -410,6 +454,7 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
                                        l0.W, l0.H, hipMemcpyDeviceToDevice, e->stream));
         e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
     }
+    e->last_stage = -1;
     return run_pipeline(e, n_images);
 }
 
@@ -552,6 +597,9 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
         HIPCHK(l, hipEventRecord(r->readers_done, l->stream));
         r->has_readers = true;
     }
+    // the L1 refinement reads both level-0 planes in place: a landing buffer is free for the next upload only after this point
+    if (l->last_stage >= 0) HIPCHK(l, hipEventRecord(l->ev_consumed[l->last_stage], l->stream));
+    if (r->last_stage >= 0) HIPCHK(l, hipEventRecord(r->ev_consumed[r->last_stage], l->stream));
     l->stereo_done = true;
     l->stereo_pairs = n;
     return JSORB_OK;
