@@ -25,13 +25,23 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// One wave64 (= one 64-thread workgroup) per left keypoint.
-//  * candidate phase: the <=3 octave ranges are merged into one flat index space so that consecutive lanes read consecutive
-//    right keypoints (coordinates and 32-byte descriptors: fully coalesced) and the dependent-load chain is paid once;
-//  * L1 phase: the 11x16 B left window and the 11x32 B right search band are staged in LDS with 3 coalesced dword-load
-//    instructions (the divergent byte gathers of a per-pixel formulation are what bound the first version: the vector
-//    memory pipeline handled ~1 lane/clk); 121 (row, shift) tasks then accumulate |(L-Lc)-(R-Rc)| from LDS and are
-//    reduced with 11 LDS atomics.
+#define SKPW 4              // left keypoints per wave
+#define SGL (64 / SKPW)     // lanes per left keypoint
+
+__device__ __forceinline__ void wave_lds_sync_st()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One wave64 (= one 64-thread workgroup) handles FOUR left keypoints, 16 lanes each: the per-keypoint scalar work (set-up,
+// scaling/rounding, parabola, depth) is issued once per four keypoints - the path is vector-issue bound.
+//  * candidate phase: the <=3 octave ranges of a keypoint are merged into one flat index space so that consecutive lanes read
+//    consecutive right keypoints (coordinates and 32-byte descriptors: coalesced) and the dependent-load chain is paid once;
+//  * L1 phase: the 11x16 B left window and the 11x32 B right search band of each keypoint are staged in LDS with coalesced
+//    dword loads (the divergent byte gathers of a per-pixel formulation bound the first version: the vector memory pipeline
+//    handled ~1 lane/clk); 121 (row, shift) tasks per keypoint accumulate |(L-Lc)-(R-Rc)| from LDS into 11 LDS counters.
 __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const uint8_t *slabL, ImageSrc srcR, const uint8_t *slabR,
                                                const int32_t *__restrict__ outL, const int *__restrict__ countsL, const uint8_t *__restrict__ descL,
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
@@ -39,25 +49,41 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
                                                unsigned *__restrict__ aux, StereoArgs sa, int n_pairs)
 {
-    __shared__ unsigned s_left[11 * 4];
-    __shared__ unsigned s_right[11 * 8];
-    __shared__ int s_acc[12];
+    __shared__ unsigned s_left_all[SKPW][11 * 4];
+    __shared__ unsigned s_right_all[SKPW][11 * 8];
+    __shared__ int s_acc_all[SKPW][12];
+    __shared__ int s_lvi[JSORB_MAX_LEVELS][8];       // th, nth, row_tab_off, W, pitch, img_off (per level, lane-indexable)
+    __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
     const int lane = threadIdx.x;
-    int b, i;
-    if (!xcd_map(blockIdx.x, g.T, n_pairs, b, i)) return;
+    const int grp = lane / SGL, sl = lane % SGL;
+    unsigned *s_left = s_left_all[grp], *s_right = s_right_all[grp];
+    int *s_acc = s_acc_all[grp];
+    int b, blk;
+    if (!xcd_map(blockIdx.x, (g.T + SKPW - 1) / SKPW, n_pairs, b, blk)) return;
     const int Nl = uniform_i32(countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
     const int Nr = uniform_i32(countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
-    if (i >= Nl) return;
+    if (blk * SKPW >= Nl) return;                     // whole wave idle
+    if (lane < g.L) {
+        const LevelDesc &lv = g.lv[lane];
+        s_lvi[lane][0] = lv.th; s_lvi[lane][1] = lv.nth; s_lvi[lane][2] = lv.row_tab_off; s_lvi[lane][3] = lv.W;
+        s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
+        s_lvf[lane][0] = lv.scale; s_lvf[lane][1] = lv.inv_scale;
+    }
+    if (sl < 11) s_acc[sl] = 0;
+    wave_lds_sync_st();
+    const int i_raw = blk * SKPW + grp;
+    const bool live = i_raw < Nl;
+    const int i = live ? i_raw : Nl - 1;              // idle groups shadow the last keypoint and write nothing
     const int32_t *oL = outL + (size_t)b * 6 * g.T;
     const int32_t *oR = outR + (size_t)b * 6 * g.T;
-    const int xL0 = uniform_i32(oL[i]), yL0 = uniform_i32(oL[Nl + i]), levelL = uniform_i32(oL[4 * (size_t)Nl + i]);
+    const int xL0 = oL[i], yL0 = oL[Nl + i], levelL = oL[4 * (size_t)Nl + i];
     const float uL = (float)xL0, vL = (float)yL0;
     const float minU = uL - sa.maxD, maxU = uL - 0.0f;
     const size_t tb = (size_t)b * g.T;
 
     unsigned best_key = 0xFFFFFFFFu;
     int n_cand = 0;
-    if (!(maxU < 0)) {
+    {
         const uint4 *dl = reinterpret_cast<const uint4 *>(descL + (tb + i) * 32);
         const uint4 a0 = dl[0], a1 = dl[1];
         const int vLi = (int)vL;
@@ -68,24 +94,25 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         for (int t = 0; t < 3; t++) {
             const int lr = levelL - 1 + t;
             j0[t] = 0; len[t] = 0; rr[t] = 0.f;
-            if (lr >= 0 && lr < g.L) {
-                const LevelDesc &lv = g.lv[lr];
-                const float r = 2.0f * lv.scale;
+            if (lr >= 0 && lr < g.L && !(maxU < 0)) {
+                const float scl = s_lvf[lr][0];
+                const int th = s_lvi[lr][0], nth = s_lvi[lr][1], rto = s_lvi[lr][2];
+                const float r = 2.0f * scl;
                 rr[t] = r;
                 // conservative tile-row window of level lr (exact tests follow per candidate)
-                const int lo = (int)__builtin_floorf((vL - r - 1.0f) / lv.scale) - 1;
-                const int hi = (int)__builtin_ceilf((vL + r + 2.0f) / lv.scale) + 1;
-                const int t_lo = lo < 0 ? 0 : lo / lv.th;
-                int t_hi = hi < 0 ? -1 : hi / lv.th;
-                if (t_hi > lv.nth - 1) t_hi = lv.nth - 1;
+                const int lo = (int)__builtin_floorf((vL - r - 1.0f) / scl) - 1;
+                const int hi = (int)__builtin_ceilf((vL + r + 2.0f) / scl) + 1;
+                const int t_lo = lo < 0 ? 0 : lo / th;
+                int t_hi = hi < 0 ? -1 : hi / th;
+                if (t_hi > nth - 1) t_hi = nth - 1;
                 if (t_lo <= t_hi) {
-                    j0[t] = uniform_i32(rt[lv.row_tab_off + t_lo]);
-                    len[t] = uniform_i32(rt[lv.row_tab_off + t_hi + 1]) - j0[t];
+                    j0[t] = rt[rto + t_lo];
+                    len[t] = rt[rto + t_hi + 1] - j0[t];
                 }
             }
         }
         const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
-        for (int k = lane; k < total; k += 64) {
+        for (int k = sl; k < total; k += SGL) {
             const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
             const int j = (t == 2 ? j0[2] - c2 : (t == 1 ? j0[1] - c1 : j0[0])) + k;
             const float r = t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]);
@@ -104,90 +131,102 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             }
         }
     }
-    best_key = (unsigned)uniform_i32((int)wave_min_u32(best_key));
-    n_cand = uniform_i32(wave_sum_i32(n_cand));
+#pragma unroll
+    for (int off = SGL / 2; off > 0; off >>= 1) {     // reduce inside the keypoint's lane group
+        const unsigned o = (unsigned)__shfl_xor((int)best_key, off, 64);
+        best_key = o < best_key ? o : best_key;
+        n_cand += __shfl_xor(n_cand, off, 64);
+    }
 
+    // ---- sub-pixel refinement of the best match (all lanes of the group hold the same values) ----
     float out_u = -1.0f, out_d = -1.0f;
     int out_l1 = -1, corr = 0;
-    if (best_key != 0xFFFFFFFFu && (int)(best_key >> 20) < sa.th_orb) {     // workgroup-uniform
-        const int bestIdxR = (int)(best_key & 0xFFFFFu);
-        const LevelDesc &lv = g.lv[levelL];
-        const float uR0 = (float)uniform_i32(oR[bestIdxR]);
-        const float scaleFactor = lv.inv_scale;
-        const float scaleduR0 = roundf(uR0 * scaleFactor);
-        const float scaleduL0 = roundf(uL * scaleFactor);
-        const float scaledvL0 = roundf(vL * scaleFactor);
-        const float iniu = scaleduR0 - 5.0f - 5.0f, endu = scaleduR0 + 5.0f + 5.0f;
-        if (!(iniu < 0 || endu >= (float)lv.W)) {
-            corr = 1;
-            const int xl = (int)scaleduL0, xr = (int)scaleduR0, y = (int)scaledvL0;
-            int pl, pr;
-            const uint8_t *imL = level_ptr(g, srcL, slabL, b, levelL, pl);
-            const uint8_t *imR = level_ptr(g, srcR, slabR, b, levelL, pr);
-            const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;      // dword aligned window starts
-            if (lane < 44) {
-                const int row = lane >> 2, dw = lane & 3;
-                const int x = la + 4 * dw;
-                s_left[lane] = (x + 4 <= pl) ? *reinterpret_cast<const unsigned *>(imL + (size_t)(y - 5 + row) * pl + x) : 0u;
+    const bool matched = best_key != 0xFFFFFFFFu && (int)(best_key >> 20) < sa.th_orb;
+    const int bestIdxR = matched ? (int)(best_key & 0xFFFFFu) : 0;
+    const float scL = s_lvf[levelL][0], iscL = s_lvf[levelL][1];
+    const int WL = s_lvi[levelL][3];
+    const float uR0 = (float)oR[bestIdxR];
+    const float scaleduR0 = roundf(uR0 * iscL);
+    const float scaleduL0 = roundf(uL * iscL);
+    const float scaledvL0 = roundf(vL * iscL);
+    const float iniu = scaleduR0 - 5.0f - 5.0f, endu = scaleduR0 + 5.0f + 5.0f;
+    const bool refine = matched && !(iniu < 0 || endu >= (float)WL);
+    if (refine) {
+        corr = 1;
+        const int xl = (int)scaleduL0, xr = (int)scaleduR0, y = (int)scaledvL0;
+        int pl, pr;
+        const uint8_t *imL, *imR;
+        if (levelL == 0) {
+            pl = srcL.l0_pitch; imL = srcL.l0 + (size_t)b * srcL.l0_stride;
+            pr = srcR.l0_pitch; imR = srcR.l0 + (size_t)b * srcR.l0_stride;
+        } else {
+            pl = pr = s_lvi[levelL][4];
+            imL = slabL + (size_t)b * g.slab_bytes + (unsigned)s_lvi[levelL][5];
+            imR = slabR + (size_t)b * g.slab_bytes + (unsigned)s_lvi[levelL][5];
+        }
+        const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;      // dword aligned window starts
+        for (int t = sl; t < 44; t += SGL) {
+            const int row = t >> 2, dw = t & 3;
+            const int x = la + 4 * dw;
+            s_left[t] = (x + 4 <= pl) ? *reinterpret_cast<const unsigned *>(imL + (size_t)(y - 5 + row) * pl + x) : 0u;
+        }
+        for (int t = sl; t < 88; t += SGL) {
+            const int row = t >> 3, dw = t & 7;
+            const int x = ra + 4 * dw;
+            s_right[t] = (x + 4 <= pr) ? *reinterpret_cast<const unsigned *>(imR + (size_t)(y - 5 + row) * pr + x) : 0u;
+        }
+    }
+    wave_lds_sync_st();
+    if (refine) {
+        const int xl = (int)scaleduL0, xr = (int)scaleduR0;
+        const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;
+        const unsigned char *bl = reinterpret_cast<const unsigned char *>(s_left) + (xl - 5 - la);
+        const unsigned char *br = reinterpret_cast<const unsigned char *>(s_right) + (xr - 10 - ra);
+        const int lc = bl[5 * 16 + 5];
+        for (int q = sl; q < 121; q += SGL) {
+            const int row = q / 11, s = q - row * 11;
+            const int rc = br[5 * 32 + 5 + s];
+            const unsigned char *pL = bl + row * 16, *pR = br + row * 32 + s;
+            int part = 0;
+#pragma unroll
+            for (int c = 0; c < 11; c++) {
+                const int df = ((int)pL[c] - lc) - ((int)pR[c] - rc);
+                part += df < 0 ? -df : df;
             }
+            atomicAdd(&s_acc[s], part);
+        }
+    }
+    wave_lds_sync_st();
+    if (refine) {
+        int acc[11];
 #pragma unroll
-            for (int t = lane; t < 88; t += 64) {
-                const int row = t >> 3, dw = t & 7;
-                const int x = ra + 4 * dw;
-                s_right[t] = (x + 4 <= pr) ? *reinterpret_cast<const unsigned *>(imR + (size_t)(y - 5 + row) * pr + x) : 0u;
-            }
-            if (lane < 11) s_acc[lane] = 0;
-            __syncthreads();
-            const unsigned char *bl = reinterpret_cast<const unsigned char *>(s_left) + (xl - 5 - la);
-            const unsigned char *br = reinterpret_cast<const unsigned char *>(s_right) + (xr - 10 - ra);
-            const int lc = bl[5 * 16 + 5];
+        for (int s = 0; s < 11; s++) acc[s] = s_acc[s];
+        int bestDist = 0x7FFFFFFF, bestR = 0;
 #pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
-                const int q = pass * 64 + lane;
-                if (q < 121) {
-                    const int row = q / 11, s = q - row * 11;
-                    const int rc = br[5 * 32 + 5 + s];
-                    const unsigned char *pL = bl + row * 16, *pR = br + row * 32 + s;
-                    int part = 0;
+        for (int s = 0; s < 11; s++)
+            if (acc[s] < bestDist) { bestDist = acc[s]; bestR = s; }
+        if (!(bestR == 0 || bestR == 10)) {
+            float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 11; c++) {
-                        const int df = ((int)pL[c] - lc) - ((int)pR[c] - rc);
-                        part += df < 0 ? -df : df;
+            for (int s = 1; s < 10; s++)
+                if (s == bestR) { dist1 = (float)acc[s - 1]; dist2 = (float)acc[s]; dist3 = (float)acc[s + 1]; }
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (!(deltaR < -1 || deltaR > 1)) {
+                float bestuR = scL * ((scaleduR0 + (float)bestR - 5.0f) + deltaR);
+                float disparity = uL - bestuR;
+                if (disparity >= 0.0f && disparity < sa.maxD) {
+                    if (disparity <= 0) {
+                        disparity = 0.01f;
+                        bestuR = (float)((double)uL - 0.01);
                     }
-                    atomicAdd(&s_acc[s], part);
-                }
-            }
-            __syncthreads();
-            int acc[11];
-#pragma unroll
-            for (int s = 0; s < 11; s++) acc[s] = uniform_i32(s_acc[s]);
-            int bestDist = 0x7FFFFFFF, bestR = 0;
-#pragma unroll
-            for (int s = 0; s < 11; s++)
-                if (acc[s] < bestDist) { bestDist = acc[s]; bestR = s; }
-            if (!(bestR == 0 || bestR == 10)) {
-                float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
-#pragma unroll
-                for (int s = 1; s < 10; s++)
-                    if (s == bestR) { dist1 = (float)acc[s - 1]; dist2 = (float)acc[s]; dist3 = (float)acc[s + 1]; }
-                const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
-                if (!(deltaR < -1 || deltaR > 1)) {
-                    float bestuR = lv.scale * ((scaleduR0 + (float)bestR - 5.0f) + deltaR);
-                    float disparity = uL - bestuR;
-                    if (disparity >= 0.0f && disparity < sa.maxD) {
-                        if (disparity <= 0) {
-                            disparity = 0.01f;
-                            bestuR = (float)((double)uL - 0.01);
-                        }
-                        out_d = sa.mbf / disparity;
-                        out_u = bestuR;
-                        out_l1 = bestDist;
-                    }
+                    out_d = sa.mbf / disparity;
+                    out_u = bestuR;
+                    out_l1 = bestDist;
                 }
             }
         }
     }
-    if (lane == 0) {
+    if (live && sl == 0) {
         u_right[tb + i] = out_u;
         depth[tb + i] = out_d;
         best_l1[tb + i] = out_l1;
@@ -298,7 +337,7 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
                    float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_stereo, dim3(xcd_grid(g.T, n_pairs)), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
+    hipLaunchKernelGGL(k_stereo, dim3(xcd_grid((g.T + SKPW - 1) / SKPW, n_pairs)), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
                        outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs);
 }
 
