@@ -244,11 +244,16 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
     // A slot of the reference's shared array always equals the current register value of its owner thread at a round
     // boundary, so for tiles that fit one wave the tree is replayed with wave shuffles (no LDS traffic, no barriers):
-    // wave w owns tiles w, w+4, ... of the group, lane j is column j of the tile.
+    // a tile occupies a power-of-two lane group (8/16/32/64 lanes), a wave replays 64/group tiles at once.
     if (tw <= 64) {
-        for (int tile = wave; tile < lv.k_tiles; tile += 4) {
-            const int col = tile * tw + lane;
-            const bool in_tile = lane < tw;
+        // sub = power-of-two lane group that holds one tile; a wave replays 64/sub tiles at once
+        const int sub = tw <= 8 ? 8 : tw <= 16 ? 16 : tw <= 32 ? 32 : 64;
+        const int tpw = 64 / sub;                         // tiles per wave-step
+        const int j = lane & (sub - 1);                   // column inside the tile
+        for (int tile0 = wave * tpw; tile0 < lv.k_tiles; tile0 += 4 * tpw) {
+            const int tile = tile0 + lane / sub;
+            const int col = tile * tw + j;
+            const bool in_tile = j < tw && tile < lv.k_tiles;
             const bool active = in_tile && (xg0 + col) < W;
             int sc = 0, yy = y0;
             if (in_tile) {
@@ -263,12 +268,13 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             int cur_sc = sc;
             int gs = (tw - 1) / 2 + 1;
             for (int it = 0; it < lv.log2_tw; it++) {
+                // lane + gs stays inside the lane group whenever j + gs < tw (the only case in which the value is used)
                 const int o_sc = __shfl_down(cur_sc, gs, 64);
                 const unsigned o_lo = (unsigned)__shfl_down((int)cur_lo, gs, 64);
-                if (active && lane < gs && lane + gs < tw && cur_sc < o_sc) { cur_sc = o_sc; cur_lo = o_lo; }
+                if (active && j < gs && j + gs < tw && cur_sc < o_sc) { cur_sc = o_sc; cur_lo = o_lo; }
                 gs = (gs - 1) / 2 + 1;
             }
-            if (active && lane == 0) {
+            if (active && j == 0) {
                 const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tile;
                 tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] = ((unsigned long long)(unsigned)cur_sc << 32) | cur_lo;
             }
