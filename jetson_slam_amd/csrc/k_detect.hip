@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         const unsigned Dm = rowp[qq - 1], D0 = rowp[qq], Dp = rowp[qq + 1];
         const unsigned Du = rowp[qq - 3 * (S >> 2)], Dd = rowp[qq + 3 * (S >> 2)];
         const int cb = 4 * qq;
-        bool pass[4];
+        int nib = 0;                                      // bit t: pixel t of this lane survives both early rejects
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int v = (int)((D0 >> (8 * t)) & 0xFFu);
@@ -167,14 +167,19 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             const bool rej = (NEAR(p4, vmt, th2) && NEAR(p12, vmt, th2)) || (NEAR(p0, vmt, th2) && NEAR(p8, vmt, th2));
             bool ok = row_ok && (unsigned)(cb + t - c_lo) < c_span && !rej;
             if (HAS_MASK) { if (ok) ok = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
-            pass[t] = ok;
+            nib |= (int)ok << t;
         }
+        // per-wave list append: one DPP prefix sum over the per-lane survivor counts instead of four ballot/popcount rounds
+        const int cnt = __popc(nib);
+        const int incl = wave_inclusive_scan_i32(cnt);
+        int pos = n_mine + incl - cnt;
+        const int e0 = (ry << 8) + (cb - c0);             // cb - c0 may be negative for the first dword; e0 + t is not
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const unsigned long long bal = __ballot(pass[t]);
-            if (pass[t]) my_list[n_mine + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((ry << 8) | (cb + t - c0));
-            n_mine += __popcll(bal);
+            if (nib & (1 << t)) my_list[pos] = (unsigned short)(e0 + t);
+            pos += (nib >> t) & 1;
         }
+        n_mine += __builtin_amdgcn_readlane(incl, 63);
     }
     if (g.dbg_stop == 2) return;
 
