@@ -269,7 +269,6 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (rc) return rc;
     Geometry &g = e->g;
     g.has_mask = mask ? 1 : 0;
-    if (const char *d = getenv("JSORB_DBG_STOP")) g.dbg_stop = atoi(d);
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;

@@ -126,7 +126,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         if (tid < 128) s_colkey[tid] = 0;
     }
     __syncthreads();
-    if (g.dbg_stop == 1) return;
 
     // ---- phase 1: the two early rejects on every pixel of the (th+2) x (ktw+2) score region, 4 pixels per lane ----
     // LDS column c <-> image x = xs + c ; region column rx <-> c = c0 + rx.  A lane owns one aligned LDS dword (4 pixels)
@@ -181,7 +180,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         }
         n_mine += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (g.dbg_stop == 2) return;
 
     // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
@@ -225,7 +223,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         n_pos += __popcll(bal);
     }
     __syncthreads();
-    if (g.dbg_stop == 3) return;
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key, positives of the wave's own list ----
     const int SW = L.score_w;
@@ -244,7 +241,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
     }
     __syncthreads();
-    if (g.dbg_stop == 4) return;
 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
     // A slot of the reference's shared array always equals the current register value of its owner thread at a round
