@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
     if (y >= H - JSORB_BORDER || x >= W - JSORB_BORDER) return;
 
     // 8 independent FMA chains, evaluated two at a time with v_pk_fma_f32 (IEEE fma per component, so each chain is still the
-    // reference's 49 sequential single-rounding FMAs).  A[j] = (acc[2j], acc[2j+1]).  For tap column c the operand pair of
-    // A[j] is (f[1+2j+c], f[2+2j+c]): register-pair aligned copies exist for both parities (Pe: even start, Po: odd start).
+    // reference's 49 sequential single-rounding FMAs).  A[j] = (acc of pixel j, acc of pixel j+4): for tap column c its operand
+    // pair is Q[1+j+c] = (f[1+j+c], f[5+j+c]) - pairs four bytes apart need no re-alignment moves, only 6 duplicate conversions.
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 A[4];
 #pragma unroll
@@ -67,34 +67,24 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
     for (int r = 0; r < 7; r++) {
         const uint2 *p = reinterpret_cast<const uint2 *>(tile + (ty + r) * BLUR_STRIDE + 8 * tx);
         const uint2 lo = p[0], hi = p[1];
-        float f[16];
+        const unsigned w4[4] = {lo.x, lo.y, hi.x, hi.y};
+        f2 Q[11];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            f[k] = (float)((lo.x >> (8 * k)) & 0xFFu);
-            f[4 + k] = (float)((lo.y >> (8 * k)) & 0xFFu);
-            f[8 + k] = (float)((hi.x >> (8 * k)) & 0xFFu);
-            f[12 + k] = (float)((hi.y >> (8 * k)) & 0xFFu);
+        for (int k = 1; k <= 10; k++) {
+            const int k2 = k + 4;
+            Q[k] = (f2){(float)((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu), (float)((w4[k2 >> 2] >> (8 * (k2 & 3))) & 0xFFu)};
         }
-        f2 Pe[8], Po[7];
-#pragma unroll
-        for (int k = 0; k < 8; k++) Pe[k] = (f2){f[2 * k], f[2 * k + 1]};
-#pragma unroll
-        for (int k = 0; k < 7; k++) Po[k] = (f2){f[2 * k + 1], f[2 * k + 2]};
 #pragma unroll
         for (int c = 0; c < 7; c++) {
             const float w = __uint_as_float(gauss_bits((r - 3) * (r - 3) + (c - 3) * (c - 3)));
             const f2 w2 = (f2){w, w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int s0 = 1 + 2 * j + c;                  // index of the first operand of the pair
-                const f2 x = (s0 & 1) ? Po[(s0 - 1) / 2] : Pe[s0 / 2];
-                A[j] = __builtin_elementwise_fma(w2, x, A[j]);
-            }
+            for (int j = 0; j < 4; j++) A[j] = __builtin_elementwise_fma(w2, Q[1 + j + c], A[j]);
         }
     }
     float acc[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { acc[2 * j] = A[j].x; acc[2 * j + 1] = A[j].y; }
+    for (int j = 0; j < 4; j++) { acc[j] = A[j].x; acc[j + 4] = A[j].y; }
     unsigned o0 = 0, o1 = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
