@@ -148,9 +148,9 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         if (lv.blur_bx == 0 || lv.blur_by == 0) { lv.blur_bx = 1; lv.blur_by = 0; }
         lv.blur_blk0 = bblk;
         bblk += lv.blur_bx * lv.blur_by;
-        lv.pyr_bx = (lv.W + 127) / 128;          // k_pyramid: 128 x 8 output tile per workgroup
+        lv.pyr_bx = (lv.W + PYR_TW - 1) / PYR_TW; // k_pyramid: PYR_TW x PYR_TH output tile per workgroup
         lv.pyr_blk0 = pblk;
-        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + 7) / 8);
+        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + PYR_TH - 1) / PYR_TH);
     }
     g.T = tiles;
     if (tiles >= (1 << 20)) { err = "too many tiles"; return JSORB_ERR_INVALID; }

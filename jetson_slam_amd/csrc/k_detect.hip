@@ -74,9 +74,6 @@ size_t detect_lds_bytes(const Geometry &g)
     return m;
 }
 
-// |a - v| <= th  <=>  (unsigned)(a - (v - th)) <= 2*th
-#define NEAR(a, vmt, th2) ((unsigned)((a) - (vmt)) <= (th2))
-
 template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
@@ -132,7 +129,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // and reads 5 dwords (left/centre/right, row-3, row+3); a wave covers two region rows per step when a row fits in 32
     // dwords.  Survivors go to a per-wave list (no atomics): 4 ballots + popcount prefix per step.
     const int threshold = g.threshold;
-    const unsigned th2 = 2u * (unsigned)threshold;
     const int c0 = (xg0 - 1) - xs;                        // LDS column of region column 0   (3 <= c0 <= 18)
     const int q0 = c0 >> 2;
     const int nq = ((c0 + L.score_w - 1) >> 2) - q0 + 1;  // dwords per region row
@@ -145,28 +141,49 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     const int rows_per_step = two_rows ? 2 : 1;
     unsigned short *my_list = s_list + wave * L.list_cap;
     int n_mine = 0;                                       // wave-uniform
+    // everything that depends only on the lane's column is loop-invariant: the dword it owns and the nibble of its pixels
+    // that lie inside [c_lo, c_hi) (interior columns of this tile group)
+    const int qq = q < nq ? q0 + q : q0;                  // keep LDS addresses in range for idle lanes
+    const int cb = 4 * qq;
+    int colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) colmask |= (int)((unsigned)(cb + t - c_lo) < c_span) << t;
+    if (q >= nq) colmask = 0;
+    // |p - v| <= th for two pixels per instruction (v_pk_sub_i16): with a = p - (v - th), "far" <=> a < 0 or 2*th - a < 0,
+    // i.e. the sign bit of (a | (2*th - a)) in each 16-bit half.  th >= 256 behaves like 256 (every pixel is "near").
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const int thc = min(threshold, 256);
+    const s2 th_pk = (s2){(short)thc, (short)thc}, th2_pk = (s2){(short)(2 * thc), (short)(2 * thc)};
+#define PK(hi, lo, sel) __builtin_bit_cast(s2, __builtin_amdgcn_perm((hi), (lo), (sel)))
     for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += 4 * rows_per_step) {
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
-        const bool row_ok = ry < L.score_rows && y >= JSORB_BORDER && y < H - JSORB_BORDER && q < nq;
-        const int qq = row_ok ? q0 + q : q0;              // keep LDS addresses in range for idle lanes
+        const bool row_ok = ry < L.score_rows && y >= JSORB_BORDER && y < H - JSORB_BORDER;
         const int rr = row_ok ? ry : 0;
         const unsigned *rowp = reinterpret_cast<const unsigned *>(s_img + (rr + 3) * S);
         const unsigned Dm = rowp[qq - 1], D0 = rowp[qq], Dp = rowp[qq + 1];
         const unsigned Du = rowp[qq - 3 * (S >> 2)], Dd = rowp[qq + 3 * (S >> 2)];
-        const int cb = 4 * qq;
         int nib = 0;                                      // bit t: pixel t of this lane survives both early rejects
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int v = (int)((D0 >> (8 * t)) & 0xFFu);
-            const int p12 = t == 3 ? (int)(D0 & 0xFFu) : (int)((Dm >> (8 * (t + 1))) & 0xFFu);
-            const int p4 = t == 0 ? (int)(D0 >> 24) : (int)((Dp >> (8 * (t - 1))) & 0xFFu);
-            const int p0 = (int)((Dd >> (8 * t)) & 0xFFu), p8 = (int)((Du >> (8 * t)) & 0xFFu);
-            const int vmt = v - threshold;
-            const bool rej = (NEAR(p4, vmt, th2) && NEAR(p12, vmt, th2)) || (NEAR(p0, vmt, th2) && NEAR(p8, vmt, th2));
-            bool ok = row_ok && (unsigned)(cb + t - c_lo) < c_span && !rej;
-            if (HAS_MASK) { if (ok) ok = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
-            nib |= (int)ok << t;
+        for (int h = 0; h < 2; h++) {                     // pixels (0,1) then (2,3); selector byte 0x0c = constant zero
+            const s2 v = PK(0u, D0, h ? 0x0c030c02u : 0x0c010c00u);
+            const s2 p12 = h ? PK(D0, Dm, 0x0c040c03u) : PK(0u, Dm, 0x0c020c01u);      // x - 3
+            const s2 p4 = h ? PK(0u, Dp, 0x0c020c01u) : PK(D0, Dp, 0x0c000c07u);       // x + 3
+            const s2 p0 = PK(0u, Dd, h ? 0x0c030c02u : 0x0c010c00u);                   // y + 3
+            const s2 p8 = PK(0u, Du, h ? 0x0c030c02u : 0x0c010c00u);                   // y - 3
+            const s2 vmt = v - th_pk;
+            const s2 a4 = p4 - vmt, a12 = p12 - vmt, a0 = p0 - vmt, a8 = p8 - vmt;
+            const s2 far_h = a4 | (th2_pk - a4) | a12 | (th2_pk - a12);                 // sign set: 4 or 12 is far from v
+            const s2 far_v = a0 | (th2_pk - a0) | a8 | (th2_pk - a8);
+            const unsigned ok = __builtin_bit_cast(unsigned, (s2)(far_h & far_v));      // !((near4 && near12) || (near0 && near8))
+            nib |= (int)((ok >> 15) & 1u) << (2 * h) | (int)(ok >> 31) << (2 * h + 1);
+        }
+        nib &= row_ok ? colmask : 0;
+        if (HAS_MASK) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if ((nib >> t) & 1)
+                    if (mask[(size_t)y * lv.pitch + xs + cb + t] == 0) nib &= ~(1 << t);
         }
         // per-wave list append: one DPP prefix sum over the per-lane survivor counts instead of four ballot/popcount rounds
         const int cnt = __popc(nib);
@@ -180,6 +197,8 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         }
         n_mine += __builtin_amdgcn_readlane(incl, 63);
     }
+
+#undef PK
 
     // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a

@@ -49,15 +49,10 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
                                                unsigned *__restrict__ aux, StereoArgs sa, int n_pairs)
 {
-    __shared__ unsigned s_left_all[SKPW][11 * 4];
-    __shared__ unsigned s_right_all[SKPW][11 * 8];
-    __shared__ int s_acc_all[SKPW][12];
     __shared__ int s_lvi[JSORB_MAX_LEVELS][8];       // th, nth, row_tab_off, W, pitch, img_off (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
     const int lane = threadIdx.x;
     const int grp = lane / SGL, sl = lane % SGL;
-    unsigned *s_left = s_left_all[grp], *s_right = s_right_all[grp];
-    int *s_acc = s_acc_all[grp];
     int b, blk;
     if (!xcd_map(blockIdx.x, (g.T + SKPW - 1) / SKPW, n_pairs, b, blk)) return;
     const int Nl = uniform_i32(countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
@@ -69,7 +64,6 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
         s_lvf[lane][0] = lv.scale; s_lvf[lane][1] = lv.inv_scale;
     }
-    if (sl < 11) s_acc[sl] = 0;
     wave_lds_sync_st();
     const int i_raw = blk * SKPW + grp;
     const bool live = i_raw < Nl;
@@ -151,11 +145,10 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
     const float scaledvL0 = roundf(vL * iscL);
     const float iniu = scaleduR0 - 5.0f - 5.0f, endu = scaleduR0 + 5.0f + 5.0f;
     const bool refine = matched && !(iniu < 0 || endu >= (float)WL);
+    int pl = 0, pr = 0;
+    const uint8_t *imL = nullptr, *imR = nullptr;
     if (refine) {
         corr = 1;
-        const int xl = (int)scaleduL0, xr = (int)scaleduR0, y = (int)scaledvL0;
-        int pl, pr;
-        const uint8_t *imL, *imR;
         if (levelL == 0) {
             pl = srcL.l0_pitch; imL = srcL.l0 + (size_t)b * srcL.l0_stride;
             pr = srcR.l0_pitch; imR = srcR.l0 + (size_t)b * srcR.l0_stride;
@@ -164,43 +157,78 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             imL = slabL + (size_t)b * g.slab_bytes + (unsigned)s_lvi[levelL][5];
             imR = slabR + (size_t)b * g.slab_bytes + (unsigned)s_lvi[levelL][5];
         }
+    }
+    // L1(s) = sum over the 11x11 window of |(L - Lc) - (R_s - Rc_s)| for the 11 shifts s.  Lane r < 11 of the keypoint's lane
+    // group owns window row r: it loads the 16 B (left) / 32 B (right) that cover its row straight from the image (dword
+    // aligned addresses, never past row y+5 <= H-16), byte-aligns them with v_alignbyte and evaluates all 11 shifts with packed
+    // 16-bit SADs: |L - (R + k_s)| with k_s = Lc - Rc_s, both sides biased by 256 so that they stay positive.  The per-row
+    // partial sums are added across the group with DPP row rotations.  No LDS: a misaligned LDS read (any access that is not
+    // naturally aligned, e.g. ds_read_b64 at a byte address) costs 64 clk per wave-instruction on gfx950 - the first version
+    // of this phase spent most of its time there.
+    int acc[11];
+#pragma unroll
+    for (int q = 0; q < 11; q++) acc[q] = 0;
+    {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+        const bool mine = refine && sl < 11;
+        const int xl = (int)scaleduL0, xr = (int)scaleduR0, y = (int)scaledvL0;
         const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;      // dword aligned window starts
-        for (int t = sl; t < 44; t += SGL) {
-            const int row = t >> 2, dw = t & 3;
-            const int x = la + 4 * dw;
-            s_left[t] = (x + 4 <= pl) ? *reinterpret_cast<const unsigned *>(imL + (size_t)(y - 5 + row) * pl + x) : 0u;
+        const unsigned shl = (unsigned)(xl - 5 - la), shr = (unsigned)(xr - 10 - ra);
+        u32x4 Lq = (u32x4){0, 0, 0, 0}, Rq0 = Lq, Rq1 = Lq;
+        if (mine) {
+            const size_t row = (size_t)(y - 5 + sl);
+            Lq = *reinterpret_cast<const u32x4 *>(imL + row * pl + la);
+            Rq0 = *reinterpret_cast<const u32x4 *>(imR + row * pr + ra);
+            Rq1 = *reinterpret_cast<const u32x4 *>(imR + row * pr + ra + 16);
         }
-        for (int t = sl; t < 88; t += SGL) {
-            const int row = t >> 3, dw = t & 7;
-            const int x = ra + 4 * dw;
-            s_right[t] = (x + 4 <= pr) ? *reinterpret_cast<const unsigned *>(imR + (size_t)(y - 5 + row) * pr + x) : 0u;
-        }
-    }
-    wave_lds_sync_st();
-    if (refine) {
-        const int xl = (int)scaleduL0, xr = (int)scaleduR0;
-        const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;
-        const unsigned char *bl = reinterpret_cast<const unsigned char *>(s_left) + (xl - 5 - la);
-        const unsigned char *br = reinterpret_cast<const unsigned char *>(s_right) + (xr - 10 - ra);
-        const int lc = bl[5 * 16 + 5];
-        for (int q = sl; q < 121; q += SGL) {
-            const int row = q / 11, s = q - row * 11;
-            const int rc = br[5 * 32 + 5 + s];
-            const unsigned char *pL = bl + row * 16, *pR = br + row * 32 + s;
-            int part = 0;
+        // window bytes 0..10 of the row in W[0..2]; search band bytes 0..20 in X[0..5]
+        unsigned W[3], X[6];
+        W[0] = __builtin_amdgcn_alignbyte(Lq.y, Lq.x, shl); W[1] = __builtin_amdgcn_alignbyte(Lq.z, Lq.y, shl);
+        W[2] = __builtin_amdgcn_alignbyte(Lq.w, Lq.z, shl);
+        X[0] = __builtin_amdgcn_alignbyte(Rq0.y, Rq0.x, shr); X[1] = __builtin_amdgcn_alignbyte(Rq0.z, Rq0.y, shr);
+        X[2] = __builtin_amdgcn_alignbyte(Rq0.w, Rq0.z, shr); X[3] = __builtin_amdgcn_alignbyte(Rq1.x, Rq0.w, shr);
+        X[4] = __builtin_amdgcn_alignbyte(Rq1.y, Rq1.x, shr); X[5] = __builtin_amdgcn_alignbyte(Rq1.z, Rq1.y, shr);
+        // centre row (window row 5) of both images: Lc = byte 5 of its W, Rc_s = byte 5+s of its X
+        const int c_lane = (lane & ~(SGL - 1)) + 5;
+        const unsigned cW1 = (unsigned)__shfl((int)W[1], c_lane, 64);
+        const unsigned cX1 = (unsigned)__shfl((int)X[1], c_lane, 64), cX2 = (unsigned)__shfl((int)X[2], c_lane, 64),
+                       cX3 = (unsigned)__shfl((int)X[3], c_lane, 64);
+        const unsigned cX[4] = {0u, cX1, cX2, cX3};
+        const int lc = (int)((cW1 >> 8) & 0xFFu);
+        // 16-bit pairs: A[m] = (L[2m], L[2m+1]) + 256 ; E[m] = (R[2m], R[2m+1]) ; O[m] = (R[2m+1], R[2m+2])
+        unsigned A[6], E[11], O[10];
 #pragma unroll
-            for (int c = 0; c < 11; c++) {
-                const int df = ((int)pL[c] - lc) - ((int)pR[c] - rc);
-                part += df < 0 ? -df : df;
+        for (int m = 0; m < 6; m++)
+            A[m] = __builtin_amdgcn_perm(0u, W[m >> 1], (m & 1) ? 0x0c030c02u : 0x0c010c00u) + 0x01000100u;
+        A[5] &= 0x0000FFFFu;                                      // the window has 11 columns: the 12th half-pair is masked
+#pragma unroll
+        for (int m = 0; m < 11; m++) E[m] = __builtin_amdgcn_perm(0u, X[m >> 1], (m & 1) ? 0x0c030c02u : 0x0c010c00u);
+#pragma unroll
+        for (int m = 0; m < 10; m++)
+            O[m] = (m & 1) ? __builtin_amdgcn_perm(X[(m + 1) >> 1], X[(m - 1) >> 1], 0x0c040c03u) : __builtin_amdgcn_perm(0u, X[m >> 1], 0x0c020c01u);
+#pragma unroll
+        for (int q = 0; q < 11; q++) {
+            const int rc = (int)((cX[(5 + q) >> 2] >> (8 * ((5 + q) & 3))) & 0xFFu);
+            const unsigned kv = (unsigned)(lc - rc + 256);         // in [1, 511]
+            const unsigned kpk = (kv << 16) | kv;
+            unsigned part = 0;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const unsigned Rp = (q & 1) ? O[(q >> 1) + m] : E[(q >> 1) + m];
+                unsigned Bp = __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, Rp) + __builtin_bit_cast(us2, kpk)));
+                if (m == 5) Bp &= 0x0000FFFFu;
+                part = __builtin_amdgcn_sad_u16(A[m], Bp, part);
             }
-            atomicAdd(&s_acc[s], part);
+            int v = mine ? (int)part : 0;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);   // row_ror:8
+            v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);   // row_ror:4
+            v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);   // row_ror:2
+            v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);   // row_ror:1 -> every lane of the group holds the sum
+            acc[q] = v;
         }
     }
-    wave_lds_sync_st();
     if (refine) {
-        int acc[11];
-#pragma unroll
-        for (int s = 0; s < 11; s++) acc[s] = s_acc[s];
         int bestDist = 0x7FFFFFFF, bestR = 0;
 #pragma unroll
         for (int s = 0; s < 11; s++)

@@ -57,7 +57,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _LIB_PATH
+    path = path or os.environ.get("JSORB_LIBRARY") or _LIB_PATH      # JSORB_LIBRARY: an alternative build of the same ABI
     if not os.path.exists(path):
         raise JsorbError("%s not found - run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % path)
     lib = C.CDLL(path)
