@@ -143,8 +143,10 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         lv.row_tab_off = rtab;
         rtab += lv.nth + 1;
         const int rw = lv.W - 2 * JSORB_BORDER, rh = lv.H - 2 * JSORB_BORDER;
-        lv.blur_bx = rw > 0 ? (rw + 63) / 64 : 0;
-        lv.blur_by = rh > 0 ? (rh + 31) / 32 : 0;
+        int btw, bth;
+        blur_tile_dims(&btw, &bth);
+        lv.blur_bx = rw > 0 ? (rw + btw - 1) / btw : 0;
+        lv.blur_by = rh > 0 ? (rh + bth - 1) / bth : 0;
         if (lv.blur_bx == 0 || lv.blur_by == 0) { lv.blur_bx = 1; lv.blur_by = 0; }
         lv.blur_blk0 = bblk;
         bblk += lv.blur_bx * lv.blur_by;
@@ -322,6 +324,9 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     {
         std::vector<uint32_t> bits;
         build_lut_bits(params->fast_n_min, params->fast_n_max, bits);
+        g.lut_min_pop = 17;
+        for (int j = 0; j < 65536; j++)
+            if ((bits[j >> 5] >> (j & 31)) & 1u) g.lut_min_pop = std::min(g.lut_min_pop, __builtin_popcount(j));
         HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (mask) {

@@ -4,25 +4,43 @@
 // [20,H-20) x [20,W-20): acc = 0; 49 chained single-rounding FMAs acc = fma(w[k], (float)I, acc) in raster order;
 // out = trunc(acc).  Pixels outside the ROI are never written and read as 0 (the blurred
 // slab is zero-filled once at create).  The weights are the hard-coded table of Appendix A.2.
-// MI355X design: a 256-thread workgroup stages a (32+6) x 80 byte tile in LDS with 190 16-byte loads; each
-// thread produces an 8-pixel strip, reading every tile row as two ds_read_b64 and converting each byte once per
-// row (14 v_cvt_f32_ubyte instead of 56); the 8 independent FMA chains interleave freely while each chain keeps
-// the reference order.
+// MI355X design: a 256-thread workgroup stages a (BLUR_TH+6) x (BLUR_TW+16) byte tile in LDS with 16-byte loads; each thread
+// produces a 16-pixel strip of 2 adjacent rows.  The kernel is vector-ALU bound (49 FMAs + the u8 -> f32 conversions per
+// pixel), so the strip is wide (22 conversions per 16 pixels per row instead of 14 per 8) and every converted input row feeds
+// both output rows; the 16 independent FMA chains of a row pair up in v_pk_fma_f32 while each chain keeps the reference order.
 #include "jsorb_launch.h"
 
 namespace jsorb {
 
 // normalised weight by squared distance d = j*j + k*k from the centre (Appendix A.2)
-__device__ __forceinline__ constexpr unsigned gauss_bits(int d)
+__host__ __device__ __forceinline__ constexpr unsigned gauss_bits(int d)
 {
     return d == 0 ? 0x3CADF459u : d == 1 ? 0x3CAD163Eu : d == 2 ? 0x3CAC393Fu : d == 4 ? 0x3CAA828Du :
            d == 5 ? 0x3CA9A8D7u : d == 8 ? 0x3CA72236u : d == 9 ? 0x3CA64CD0u : d == 10 ? 0x3CA5787Bu :
            d == 13 ? 0x3CA301D1u : 0x3C9EFB81u /* d == 18 */;
 }
 
+// weight of tap (r, c) = c_gauss[r][|c - 3|]
+__constant__ unsigned c_gauss_bits[7][4] = {
+    {gauss_bits(9 + 0), gauss_bits(9 + 1), gauss_bits(9 + 4), gauss_bits(9 + 9)}, {gauss_bits(4 + 0), gauss_bits(4 + 1), gauss_bits(4 + 4), gauss_bits(4 + 9)},
+    {gauss_bits(1 + 0), gauss_bits(1 + 1), gauss_bits(1 + 4), gauss_bits(1 + 9)}, {gauss_bits(0 + 0), gauss_bits(0 + 1), gauss_bits(0 + 4), gauss_bits(0 + 9)},
+    {gauss_bits(1 + 0), gauss_bits(1 + 1), gauss_bits(1 + 4), gauss_bits(1 + 9)}, {gauss_bits(4 + 0), gauss_bits(4 + 1), gauss_bits(4 + 4), gauss_bits(4 + 9)},
+    {gauss_bits(9 + 0), gauss_bits(9 + 1), gauss_bits(9 + 4), gauss_bits(9 + 9)}};
+#define c_gauss reinterpret_cast<const float (*)[4]>(c_gauss_bits)
+
+// strip of BLUR_STRIP pixels x BLUR_ROWS rows per thread; 256 threads cover a BLUR_TW x BLUR_TH tile
+#ifndef BLUR_STRIP
+#define BLUR_STRIP 16
+#endif
+#ifndef BLUR_ROWS
+#define BLUR_ROWS 2
+#endif
+#ifndef BLUR_TW
 #define BLUR_TW 64
-#define BLUR_TH 32
-#define BLUR_STRIDE 80
+#endif
+#define BLUR_TH (256 * BLUR_ROWS * BLUR_STRIP / BLUR_TW)
+#define BLUR_STRIDE (BLUR_TW + 16)
+#define BLUR_HALF (BLUR_STRIP / 2)
 
 __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, int n_images)
 {
@@ -42,66 +60,96 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
     int pitch;
     const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
 
-    // 16-byte staging loads (x0 - 4 is a multiple of 16: x0 = 20 + 64*bx); a tile row is 5 x 16 B
-    if (tid < (BLUR_TH + 6) * (BLUR_STRIDE / 16)) {
-        const int ly = tid / (BLUR_STRIDE / 16), dx = tid - ly * (BLUR_STRIDE / 16);
+    // 16-byte staging loads (x0 - 4 is a multiple of 16: x0 = 20 + BLUR_TW*bx)
+    constexpr int NQ = BLUR_STRIDE / 16;
+    for (int i = tid; i < (BLUR_TH + 6) * NQ; i += 256) {
+        const int ly = i / NQ, dx = i - ly * NQ;
         const int y = y0 - 3 + ly, x = x0 - 4 + 16 * dx;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (y < H && x + 16 <= pitch) v = *reinterpret_cast<const uint4 *>(img + (size_t)y * pitch + x);
-        reinterpret_cast<uint4 *>(tile)[tid] = v;
+        reinterpret_cast<uint4 *>(tile)[i] = v;
     }
     __syncthreads();
 
-    const int ty = tid >> 3, tx = tid & 7;
-    const int y = y0 + ty, x = x0 + 8 * tx;
+    constexpr int SPR = BLUR_TW / BLUR_STRIP;         // strips per tile row
+    const int ty = tid / SPR, tx = tid % SPR;
+    const int y = y0 + BLUR_ROWS * ty, x = x0 + BLUR_STRIP * tx;
     if (y >= H - JSORB_BORDER || x >= W - JSORB_BORDER) return;
 
-    // 8 independent FMA chains, evaluated two at a time with v_pk_fma_f32 (IEEE fma per component, so each chain is still the
-    // reference's 49 sequential single-rounding FMAs).  A[j] = (acc of pixel j, acc of pixel j+4): for tap column c its operand
-    // pair is Q[1+j+c] = (f[1+j+c], f[5+j+c]) - pairs four bytes apart need no re-alignment moves, only 6 duplicate conversions.
+    // BLUR_STRIP independent FMA chains per output row, evaluated two at a time with v_pk_fma_f32 (IEEE fma per component, so each
+    // chain is still the reference's 49 sequential single-rounding FMAs).  A[o][j] = (acc of pixel j, acc of pixel j + HALF): for
+    // tap column c its operand pair is Q[1+j+c] = (f[1+j+c], f[1+j+c+HALF]) - pairs HALF bytes apart need no re-alignment moves.
+    // The kernel is vector-ALU bound and the u8 -> f32 conversions are ~40 % of it, so a thread owns a wide strip (fewer halo
+    // conversions) of BLUR_ROWS adjacent rows (each converted input row feeds both output rows).
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 A[4];
+    f2 A[BLUR_ROWS][BLUR_HALF];
 #pragma unroll
-    for (int j = 0; j < 4; j++) A[j] = (f2){0.0f, 0.0f};
+    for (int o = 0; o < BLUR_ROWS; o++)
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
-        const uint2 *p = reinterpret_cast<const uint2 *>(tile + (ty + r) * BLUR_STRIDE + 8 * tx);
-        const uint2 lo = p[0], hi = p[1];
-        const unsigned w4[4] = {lo.x, lo.y, hi.x, hi.y};
-        f2 Q[11];
+        for (int j = 0; j < BLUR_HALF; j++) A[o][j] = (f2){0.0f, 0.0f};
+    // The row loop is NOT unrolled: fully unrolled, the compiler's schedule needs 140-200 VGPRs for BLUR_ROWS = 2 (2-3 waves per
+    // SIMD), and this kernel needs the occupancy to overlap the staging phase of one workgroup with the arithmetic of the
+    // others.  Rolled, the weights of tap row r come from a constant table through scalar loads; one LDS row is prefetched.
+    constexpr int NW = BLUR_STRIP / 4 + 2;
+    unsigned nxt[NW];
+    const unsigned char *rowp = tile + (BLUR_ROWS * ty) * BLUR_STRIDE + BLUR_STRIP * tx;
 #pragma unroll
-        for (int k = 1; k <= 10; k++) {
-            const int k2 = k + 4;
+    for (int k = 0; k < NW / 2; k++) { const uint2 v = reinterpret_cast<const uint2 *>(rowp)[k]; nxt[2 * k] = v.x; nxt[2 * k + 1] = v.y; }
+#pragma unroll 1
+    for (int i = 0; i < 6 + BLUR_ROWS; i++) {          // input row y - 3 + i
+        unsigned w4[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) w4[k] = nxt[k];
+        rowp += BLUR_STRIDE;
+        if (i + 1 < 6 + BLUR_ROWS) {
+#pragma unroll
+            for (int k = 0; k < NW / 2; k++) { const uint2 v = reinterpret_cast<const uint2 *>(rowp)[k]; nxt[2 * k] = v.x; nxt[2 * k + 1] = v.y; }
+        }
+        f2 Q[BLUR_HALF + 7];
+#pragma unroll
+        for (int k = 1; k <= BLUR_HALF + 6; k++) {
+            const int k2 = k + BLUR_HALF;
             Q[k] = (f2){(float)((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu), (float)((w4[k2 >> 2] >> (8 * (k2 & 3))) & 0xFFu)};
         }
 #pragma unroll
-        for (int c = 0; c < 7; c++) {
-            const float w = __uint_as_float(gauss_bits((r - 3) * (r - 3) + (c - 3) * (c - 3)));
-            const f2 w2 = (f2){w, w};
+        for (int o = 0; o < BLUR_ROWS; o++) {
+            const int r = i - o;                      // tap row of output row o (wave-uniform)
+            if (r < 0 || r > 6) continue;
+            const float wr[4] = {c_gauss[r][0], c_gauss[r][1], c_gauss[r][2], c_gauss[r][3]};
 #pragma unroll
-            for (int j = 0; j < 4; j++) A[j] = __builtin_elementwise_fma(w2, Q[1 + j + c], A[j]);
+            for (int c = 0; c < 7; c++) {
+                const float w = wr[c < 3 ? 3 - c : c - 3];
+                const f2 w2 = (f2){w, w};
+#pragma unroll
+                for (int j = 0; j < BLUR_HALF; j++) A[o][j] = __builtin_elementwise_fma(w2, Q[1 + j + c], A[o][j]);
+            }
         }
     }
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { acc[j] = A[j].x; acc[j + 4] = A[j].y; }
-    unsigned o0 = 0, o1 = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        o0 |= ((unsigned)acc[j] & 0xFFu) << (8 * j);
-        o1 |= ((unsigned)acc[4 + j] & 0xFFu) << (8 * j);
-    }
-    uint8_t *dst = blur_slab + (size_t)b * g.slab_bytes + lv.img_off + (size_t)y * lv.pitch + x;
     const int n_valid = (W - JSORB_BORDER) - x;      // pixels of the strip inside the ROI
-    if (n_valid >= 8) {
-        reinterpret_cast<unsigned *>(dst)[0] = o0;
-        reinterpret_cast<unsigned *>(dst)[1] = o1;
-    } else {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (j < n_valid) dst[j] = (uint8_t)(((j < 4 ? o0 : o1) >> (8 * (j & 3))) & 0xFFu);
+    for (int o = 0; o < BLUR_ROWS; o++) {
+        if (y + o >= H - JSORB_BORDER) break;
+        unsigned ow[BLUR_STRIP / 4];
+#pragma unroll
+        for (int k = 0; k < BLUR_STRIP / 4; k++) ow[k] = 0;
+#pragma unroll
+        for (int j = 0; j < BLUR_HALF; j++) {
+            ow[j >> 2] |= ((unsigned)A[o][j].x & 0xFFu) << (8 * (j & 3));
+            ow[(j + BLUR_HALF) >> 2] |= ((unsigned)A[o][j].y & 0xFFu) << (8 * ((j + BLUR_HALF) & 3));
+        }
+        uint8_t *dst = blur_slab + (size_t)b * g.slab_bytes + lv.img_off + (size_t)(y + o) * lv.pitch + x;
+        if (n_valid >= BLUR_STRIP) {
+#pragma unroll
+            for (int k = 0; k < BLUR_STRIP / 4; k++) reinterpret_cast<unsigned *>(dst)[k] = ow[k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < BLUR_STRIP; j++)
+                if (j < n_valid) dst[j] = (uint8_t)((ow[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+        }
     }
 }
+
+void blur_tile_dims(int *tw, int *th) { *tw = BLUR_TW; *th = BLUR_TH; }
 
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s)
 {

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
     // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
     const int lx_off = c0;
+    const int min_pop = g.lut_min_pop;
     int n_pos = 0;                                        // wave-uniform
     for (int i0 = 0; i0 < n_mine; i0 += 64) {
         const int i = i0 + lane;
@@ -227,7 +228,13 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
                 bright = __builtin_amdgcn_alignbit(bright, (unsigned)(vt - p[k]), 31);
                 dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p[k] - v_t), 31);
             }
-            hit = (((lut_bits[bright >> 5] >> (bright & 31)) | (lut_bits[dark >> 5] >> (dark & 31))) & 1u) != 0;
+            // arc LUT (8 KB bit table, global): a divergent dword gather costs the vector-memory pipeline ~1 lane/clk, so masks
+            // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
+            // of them is ever looked up, usually none)
+            unsigned lb = 0;
+            if (__popc(bright) >= min_pop) lb = lut_bits[bright >> 5] >> (bright & 31);
+            if (__popc(dark) >= min_pop) lb |= lut_bits[dark >> 5] >> (dark & 31);
+            hit = (lb & 1u) != 0;
             if (hit) {
                 const unsigned v4 = (unsigned)v * 0x01010101u;
                 unsigned sad = 0;
