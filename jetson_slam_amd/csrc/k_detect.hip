@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         if (tid < 128) s_colkey[tid] = 0;
     }
     __syncthreads();
+#if defined(DET_STOP) && DET_STOP == 0
+    if (n_images > 0) { if (s_img[tid] == 77 && s_score[tid] == 9) tile_out[0] = 1; return; }
+#endif
 
     // ---- phase 1: the two early rejects on every pixel of the (th+2) x (ktw+2) score region, 4 pixels per lane ----
     // LDS column c <-> image x = xs + c ; region column rx <-> c = c0 + rx.  A lane owns one aligned LDS dword (4 pixels)
@@ -200,6 +203,9 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 
 #undef PK
 
+#if defined(DET_STOP) && DET_STOP == 1
+    if (n_images > 0) { if (n_mine == 12345) tile_out[0] = 1; return; }
+#endif
     // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
     // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
@@ -249,6 +255,9 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         n_pos += __popcll(bal);
     }
     __syncthreads();
+#if defined(DET_STOP) && DET_STOP == 2
+    if (n_images > 0) return;
+#endif
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key, positives of the wave's own list ----
     const int SW = L.score_w;
@@ -267,6 +276,9 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
     }
     __syncthreads();
+#if defined(DET_STOP) && DET_STOP == 3
+    if (n_images > 0) return;
+#endif
 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
     // A slot of the reference's shared array always equals the current register value of its owner thread at a round
