@@ -325,8 +325,13 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         std::vector<uint32_t> bits;
         build_lut_bits(params->fast_n_min, params->fast_n_max, bits);
         g.lut_min_pop = 17;
+        g.lut_compass = 1;
         for (int j = 0; j < 65536; j++)
-            if ((bits[j >> 5] >> (j & 31)) & 1u) g.lut_min_pop = std::min(g.lut_min_pop, __builtin_popcount(j));
+            if ((bits[j >> 5] >> (j & 31)) & 1u) {
+                g.lut_min_pop = std::min(g.lut_min_pop, __builtin_popcount(j));
+                const int m0 = j & 1, m4 = (j >> 4) & 1, m8 = (j >> 8) & 1, m12 = (j >> 12) & 1;
+                if (!((m0 | m8) & (m4 | m12))) g.lut_compass = 0;
+            }
         HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (mask) {

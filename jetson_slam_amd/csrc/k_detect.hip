@@ -74,7 +74,7 @@ size_t detect_lds_bytes(const Geometry &g)
     return m;
 }
 
-template <bool HAS_MASK>
+template <bool HAS_MASK, bool COMPASS>
 __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
 {
@@ -123,9 +123,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         if (tid < 128) s_colkey[tid] = 0;
     }
     __syncthreads();
-#if defined(DET_STOP) && DET_STOP == 0
-    if (n_images > 0) { if (s_img[tid] == 77 && s_score[tid] == 9) tile_out[0] = 1; return; }
-#endif
 
     // ---- phase 1: the two early rejects on every pixel of the (th+2) x (ktw+2) score region, 4 pixels per lane ----
     // LDS column c <-> image x = xs + c ; region column rx <-> c = c0 + rx.  A lane owns one aligned LDS dword (4 pixels)
@@ -176,9 +173,17 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             const s2 p8 = PK(0u, Du, h ? 0x0c030c02u : 0x0c010c00u);                   // y - 3
             const s2 vmt = v - th_pk;
             const s2 a4 = p4 - vmt, a12 = p12 - vmt, a0 = p0 - vmt, a8 = p8 - vmt;
-            const s2 far_h = a4 | (th2_pk - a4) | a12 | (th2_pk - a12);                 // sign set: 4 or 12 is far from v
-            const s2 far_v = a0 | (th2_pk - a0) | a8 | (th2_pk - a8);
-            const unsigned ok = __builtin_bit_cast(unsigned, (s2)(far_h & far_v));      // !((near4 && near12) || (near0 && near8))
+            const s2 b4 = th2_pk - a4, b12 = th2_pk - a12, b0 = th2_pk - a0, b8 = th2_pk - a8;    // sign of a: darker, sign of b: brighter
+            unsigned ok;
+            if (COMPASS) {
+                // every mask the arc LUT accepts has two adjacent compass pixels of the same polarity (host-checked property of
+                // the LUT): a strict subset of the reference's early rejects that still contains every pixel with a positive score
+                ok = __builtin_bit_cast(unsigned, (s2)(((b4 | b12) & (b0 | b8)) | ((a4 | a12) & (a0 | a8))));
+            } else {
+                const s2 far_h = a4 | b4 | a12 | b12;                                   // sign set: 4 or 12 is far from v
+                const s2 far_v = a0 | b0 | a8 | b8;
+                ok = __builtin_bit_cast(unsigned, (s2)(far_h & far_v));                // !((near4 && near12) || (near0 && near8))
+            }
             nib |= (int)((ok >> 15) & 1u) << (2 * h) | (int)(ok >> 31) << (2 * h + 1);
         }
         nib &= row_ok ? colmask : 0;
@@ -203,9 +208,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 
 #undef PK
 
-#if defined(DET_STOP) && DET_STOP == 1
-    if (n_images > 0) { if (n_mine == 12345) tile_out[0] = 1; return; }
-#endif
     // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
     // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
@@ -255,9 +257,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         n_pos += __popcll(bal);
     }
     __syncthreads();
-#if defined(DET_STOP) && DET_STOP == 2
-    if (n_images > 0) return;
-#endif
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key, positives of the wave's own list ----
     const int SW = L.score_w;
@@ -276,9 +275,6 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
     }
     __syncthreads();
-#if defined(DET_STOP) && DET_STOP == 3
-    if (n_images > 0) return;
-#endif
 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
     // A slot of the reference's shared array always equals the current register value of its owner thread at a round
@@ -360,10 +356,10 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
-    if (g.has_mask)
-        hipLaunchKernelGGL(k_detect<true>, dim3(xcd_grid(g.detect_blocks, n_images)), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images);
-    else
-        hipLaunchKernelGGL(k_detect<false>, dim3(xcd_grid(g.detect_blocks, n_images)), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images);
+#define DETECT_LAUNCH(M, C) hipLaunchKernelGGL((k_detect<M, C>), dim3(xcd_grid(g.detect_blocks, n_images)), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
+    if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH(true, true); else DETECT_LAUNCH(true, false); }
+    else            { if (g.lut_compass) DETECT_LAUNCH(false, true); else DETECT_LAUNCH(false, false); }
+#undef DETECT_LAUNCH
 }
 
 } // namespace jsorb
