@@ -108,13 +108,24 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     //  ~16 clk whatever its width, so staging uses global_load_dwordx4 / ds_write_b128 throughout)
     constexpr int S = DET_S;
     const int xs = (xg0 - 4) & ~15;                       // 16-byte aligned (may be negative)
-    constexpr int nq16 = S >> 4;
-    for (int i = tid; i < L.img_rows * nq16; i += 256) {
-        const int ly = i / nq16, dx = i - ly * nq16;
-        const int y = y0 - 4 + ly, x = xs + 16 * dx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (y >= 0 && y < H && x >= 0 && x + 16 <= pitch) v = *reinterpret_cast<const uint4 *>(img + (size_t)y * pitch + x);
-        reinterpret_cast<uint4 *>(s_img)[i] = v;
+    constexpr int nq16 = S >> 4;                          // 10 units of 16 B per LDS row
+    constexpr int rpp = 256 / nq16;                       // 25 rows per pass (250 of the 256 threads)
+    {
+        // a thread keeps its column and walks down the tile with a constant pointer stride: no per-item index arithmetic
+        const int dx = tid % nq16, ly0 = tid / nq16;
+        const int x = xs + 16 * dx;
+        const bool x_ok = tid < rpp * nq16 && x >= 0 && x + 16 <= pitch;
+        const uint8_t *p16 = img + (ptrdiff_t)(y0 - 4 + ly0) * pitch + x;
+        uint4 *dst = reinterpret_cast<uint4 *>(s_img) + tid;
+        int y = y0 - 4 + ly0;
+        for (int ly = ly0; ly < L.img_rows; ly += rpp) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (x_ok && y >= 0 && y < H) v = *reinterpret_cast<const uint4 *>(p16);
+            if (tid < rpp * nq16) *dst = v;
+            p16 += (size_t)rpp * pitch;
+            dst += rpp * nq16;
+            y += rpp;
+        }
     }
     {
         const int nsc = (L.score_w * L.score_rows * 2 + 15) >> 4;
@@ -145,10 +156,11 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // that lie inside [c_lo, c_hi) (interior columns of this tile group)
     const int qq = q < nq ? q0 + q : q0;                  // keep LDS addresses in range for idle lanes
     const int cb = 4 * qq;
-    int colmask = 0;
+    // cm[h]: sign-bit positions (bit 15 = pixel 2h, bit 31 = pixel 2h+1) of the lane's pixels that lie inside [c_lo, c_hi)
+    unsigned cm[2] = {0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 4; t++) colmask |= (int)((unsigned)(cb + t - c_lo) < c_span) << t;
-    if (q >= nq) colmask = 0;
+    for (int t = 0; t < 4; t++)
+        if (q < nq && (unsigned)(cb + t - c_lo) < c_span) cm[t >> 1] |= (t & 1) ? 0x80000000u : 0x8000u;
     // |p - v| <= th for two pixels per instruction (v_pk_sub_i16): with a = p - (v - th), "far" <=> a < 0 or 2*th - a < 0,
     // i.e. the sign bit of (a | (2*th - a)) in each 16-bit half.  th >= 256 behaves like 256 (every pixel is "near").
     typedef short s2 __attribute__((ext_vector_type(2)));
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         const unsigned *rowp = reinterpret_cast<const unsigned *>(s_img + (rr + 3) * S);
         const unsigned Dm = rowp[qq - 1], D0 = rowp[qq], Dp = rowp[qq + 1];
         const unsigned Du = rowp[qq - 3 * (S >> 2)], Dd = rowp[qq + 3 * (S >> 2)];
-        int nib = 0;                                      // bit t: pixel t of this lane survives both early rejects
+        unsigned okw[2];                                  // sign bits (15 / 31): pixel 2h / 2h+1 survives both early rejects
 #pragma unroll
         for (int h = 0; h < 2; h++) {                     // pixels (0,1) then (2,3); selector byte 0x0c = constant zero
             const s2 v = PK(0u, D0, h ? 0x0c030c02u : 0x0c010c00u);
@@ -184,28 +196,21 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
                 const s2 far_v = a0 | b0 | a8 | b8;
                 ok = __builtin_bit_cast(unsigned, (s2)(far_h & far_v));                // !((near4 && near12) || (near0 && near8))
             }
-            nib |= (int)((ok >> 15) & 1u) << (2 * h) | (int)(ok >> 31) << (2 * h + 1);
+            okw[h] = ok & (row_ok ? cm[h] : 0u);
         }
-        nib &= row_ok ? colmask : 0;
-        if (HAS_MASK) {
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                if ((nib >> t) & 1)
-                    if (mask[(size_t)y * lv.pitch + xs + cb + t] == 0) nib &= ~(1 << t);
-        }
-        // per-wave list append: one DPP prefix sum over the per-lane survivor counts instead of four ballot/popcount rounds
-        const int cnt = __popc(nib);
-        const int incl = wave_inclusive_scan_i32(cnt);
-        int pos = n_mine + incl - cnt;
+        // per-wave list append, one ballot per pixel slot: position = n_mine + (survivors of this slot in lower lanes), which
+        // v_mbcnt delivers with the base folded in; the survivor count is scalar (s_bcnt1).  Entry order inside the list is free.
         const int e0 = (ry << 8) + (cb - c0);             // cb - c0 may be negative for the first dword; e0 + t is not
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            if (nib & (1 << t)) my_list[pos] = (unsigned short)(e0 + t);
-            pos += (nib >> t) & 1;
+            bool keep = (t & 1) ? (int)okw[t >> 1] < 0 : (okw[t >> 1] & 0x8000u) != 0;
+            if (HAS_MASK) { if (keep) keep = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
+            const unsigned long long bal = __ballot(keep);
+            const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, (unsigned)n_mine));
+            if (keep) my_list[pos] = (unsigned short)(e0 + t);
+            n_mine += __popcll(bal);
         }
-        n_mine += __builtin_amdgcn_readlane(incl, 63);
     }
-
 #undef PK
 
     // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----

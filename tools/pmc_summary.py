@@ -5,7 +5,7 @@ for path in sys.argv[1:]:
     for f in sorted(glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("jsorb::", "")
+            k = r["Kernel_Name"].split("(")[0].replace("jsorb::", "").replace("void ", "").split("<")[0]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print("==", f)
         for k, d in acc.items():

@@ -19,7 +19,7 @@ def counters(sub):
 stats = []
 for f in glob.glob(os.path.join(O, tag + "_trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Name"].split("(")[0].replace("jsorb::", "").replace("void ", "")
+        name = r["Name"].split("(")[0].replace("jsorb::", "").replace("void ", "").split("<")[0]
         stats.append((name, int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"])))
 stats.sort(key=lambda t: -t[1] * t[2])
 with open(os.path.join(O, tag + "_kernel_stats.csv"), "w") as f:
