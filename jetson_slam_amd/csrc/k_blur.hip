@@ -87,44 +87,48 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
     for (int o = 0; o < BLUR_ROWS; o++)
 #pragma unroll
         for (int j = 0; j < BLUR_HALF; j++) A[o][j] = (f2){0.0f, 0.0f};
-    // The row loop is NOT unrolled: fully unrolled, the compiler's schedule needs 140-200 VGPRs for BLUR_ROWS = 2 (2-3 waves per
-    // SIMD), and this kernel needs the occupancy to overlap the staging phase of one workgroup with the arithmetic of the
-    // others.  Rolled, the weights of tap row r come from a constant table through scalar loads; one LDS row is prefetched.
+    // The row loop is NOT fully unrolled: unrolled, the compiler's schedule needs 140-200 VGPRs (2-3 waves per SIMD), and this
+    // kernel needs the occupancy to overlap the staging phase of one workgroup with the arithmetic of the others.  The weights
+    // of tap row r come from a constant table through scalar loads.  Input rows 0 and 7 feed one output row each and are peeled;
+    // rows 1..6 feed both and run as 3 iterations of two rows with two ping-pong row buffers (no register copies, no branches).
+    static_assert(BLUR_ROWS == 2, "the row schedule below is written for two output rows per thread");
     constexpr int NW = BLUR_STRIP / 4 + 2;
-    unsigned nxt[NW];
     const unsigned char *rowp = tile + (BLUR_ROWS * ty) * BLUR_STRIDE + BLUR_STRIP * tx;
+    auto load_row = [&](unsigned (&w)[NW], int row) {
 #pragma unroll
-    for (int k = 0; k < NW / 2; k++) { const uint2 v = reinterpret_cast<const uint2 *>(rowp)[k]; nxt[2 * k] = v.x; nxt[2 * k + 1] = v.y; }
-#pragma unroll 1
-    for (int i = 0; i < 6 + BLUR_ROWS; i++) {          // input row y - 3 + i
-        unsigned w4[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) w4[k] = nxt[k];
-        rowp += BLUR_STRIDE;
-        if (i + 1 < 6 + BLUR_ROWS) {
-#pragma unroll
-            for (int k = 0; k < NW / 2; k++) { const uint2 v = reinterpret_cast<const uint2 *>(rowp)[k]; nxt[2 * k] = v.x; nxt[2 * k + 1] = v.y; }
-        }
-        f2 Q[BLUR_HALF + 7];
+        for (int k = 0; k < NW / 2; k++) { const uint2 v = reinterpret_cast<const uint2 *>(rowp + row * BLUR_STRIDE)[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    };
+    auto convert = [&](const unsigned (&w)[NW], f2 (&Q)[BLUR_HALF + 7]) {
 #pragma unroll
         for (int k = 1; k <= BLUR_HALF + 6; k++) {
             const int k2 = k + BLUR_HALF;
-            Q[k] = (f2){(float)((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu), (float)((w4[k2 >> 2] >> (8 * (k2 & 3))) & 0xFFu)};
+            Q[k] = (f2){(float)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu), (float)((w[k2 >> 2] >> (8 * (k2 & 3))) & 0xFFu)};
         }
+    };
+    auto accum = [&](f2 (&acc)[BLUR_HALF], const f2 (&Q)[BLUR_HALF + 7], int r) {      // r: tap row (wave-uniform)
+        const float wr[4] = {c_gauss[r][0], c_gauss[r][1], c_gauss[r][2], c_gauss[r][3]};
 #pragma unroll
-        for (int o = 0; o < BLUR_ROWS; o++) {
-            const int r = i - o;                      // tap row of output row o (wave-uniform)
-            if (r < 0 || r > 6) continue;
-            const float wr[4] = {c_gauss[r][0], c_gauss[r][1], c_gauss[r][2], c_gauss[r][3]};
+        for (int c = 0; c < 7; c++) {
+            const float w = wr[c < 3 ? 3 - c : c - 3];
+            const f2 w2 = (f2){w, w};
 #pragma unroll
-            for (int c = 0; c < 7; c++) {
-                const float w = wr[c < 3 ? 3 - c : c - 3];
-                const f2 w2 = (f2){w, w};
-#pragma unroll
-                for (int j = 0; j < BLUR_HALF; j++) A[o][j] = __builtin_elementwise_fma(w2, Q[1 + j + c], A[o][j]);
-            }
+            for (int j = 0; j < BLUR_HALF; j++) acc[j] = __builtin_elementwise_fma(w2, Q[1 + j + c], acc[j]);
         }
+    };
+    unsigned wa[NW], wb[NW];
+    f2 Q[BLUR_HALF + 7];
+    load_row(wa, 0);
+    load_row(wb, 1);
+    convert(wa, Q); accum(A[0], Q, 0);                 // input row 0: tap row 0 of output row 0
+    load_row(wa, 2);
+#pragma unroll 1
+    for (int i = 1; i < 7; i += 2) {                   // input rows i (in wb) and i + 1 (in wa)
+        convert(wb, Q); accum(A[0], Q, i); accum(A[1], Q, i - 1);
+        load_row(wb, i + 2);                           // rows 3, 5, 7
+        convert(wa, Q); accum(A[0], Q, i + 1); accum(A[1], Q, i);
+        load_row(wa, i + 3 < 8 ? i + 3 : 7);           // rows 4, 6 (the last load is unused)
     }
+    convert(wb, Q); accum(A[1], Q, 6);                 // input row 7: tap row 6 of output row 1
     const int n_valid = (W - JSORB_BORDER) - x;      // pixels of the strip inside the ROI
 #pragma unroll
     for (int o = 0; o < BLUR_ROWS; o++) {
