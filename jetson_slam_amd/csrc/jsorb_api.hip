@@ -276,6 +276,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     e->stream = e->own_stream;
     HIPCHK(e, hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->readers_done, hipEventDisableTiming));
+    fill_detect_layout(g);
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
     e->pyr_lds = pyramid_lds_bytes(g);
@@ -294,7 +295,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
             HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k], hipEventDisableTiming));
         }
     }
-    HIPCHK(e, hipMalloc(&e->lut_bits, 2048 * sizeof(uint32_t)));
+    HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks) * sizeof(uint32_t)));      // arc LUT + k_detect workgroup table
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
     HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
@@ -332,7 +333,13 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
                 const int m0 = j & 1, m4 = (j >> 4) & 1, m8 = (j >> 8) & 1, m12 = (j >> 12) & 1;
                 if (!((m0 | m8) & (m4 | m12))) g.lut_compass = 0;
             }
-        HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // k_detect workgroup table: level | tile row << 4 | tile group << 18
+        bits.resize(2048 + (size_t)g.detect_blocks);
+        for (int i = 0; i < g.L; i++)
+            for (int r = 0; r < g.lv[i].nth; r++)
+                for (int gr = 0; gr < g.lv[i].groups_per_row; gr++)
+                    bits[2048 + g.lv[i].detect_blk0 + r * g.lv[i].groups_per_row + gr] = (uint32_t)i | ((uint32_t)r << 4) | ((uint32_t)gr << 18);
+        HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (mask) {
         // orb_gpu.cpp:64-91: nearest-neighbour resample per level, then threshold (>10 -> 255).  OpenCV is not available; the

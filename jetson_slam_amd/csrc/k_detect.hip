@@ -64,6 +64,16 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     return d;
 }
 
+void fill_detect_layout(Geometry &g)
+{
+    for (int i = 0; i < g.L; i++) {
+        LevelDesc &lv = g.lv[i];
+        const DetectLds d = detect_lds_layout(lv.th, lv.tw, lv.k_tiles);
+        lv.det_score_w = d.score_w; lv.det_score_rows = d.score_rows; lv.det_img_rows = d.img_rows; lv.det_list_cap = d.list_cap;
+        lv.det_off_score = (int)d.off_score; lv.det_off_list = (int)d.off_list; lv.det_off_colkey = (int)d.off_colkey; lv.det_off_tree = (int)d.off_tree;
+    }
+}
+
 size_t detect_lds_bytes(const Geometry &g)
 {
     size_t m = 0;
@@ -80,20 +90,24 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
+    // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
+    asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
     int b, blk;
     if (!xcd_map(blockIdx.x, g.detect_blocks, n_images, b, blk)) return;
-    int lvl = 0;
-#pragma unroll 1
-    for (int i = 1; i < g.L; i++)
-        if (blk >= g.lv[i].detect_blk0) lvl = i;
+    // workgroup descriptor (level, tile row, tile group) from the host-built table behind the LUT: one scalar load instead of a
+    // chain of dependent ones - the kernel is sensitive to the latency of this prologue (no vector work can start before it)
+    const unsigned wd = reinterpret_cast<const unsigned __attribute__((address_space(4))) *>(reinterpret_cast<size_t>(lut_bits))[2048 + blk];      // constant address space: s_load
+    const int lvl = (int)(wd & 15u), r = (int)((wd >> 4) & 0x3FFFu), grp = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
     const int H = lv.H, W = lv.W, th = lv.th, tw = lv.tw;
-    const int lb = blk - lv.detect_blk0;
-    const int r = lb / lv.groups_per_row, grp = lb % lv.groups_per_row;
+    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(lv.det_img_rows), "s"(H), "s"(th));       // one round of loads
     const int ktw = lv.k_tiles * tw;
     const int xg0 = grp * ktw;            // first image column of the tile group
     const int y0 = r * th;                // first image row of the tile row
-    const DetectLds L = detect_lds_layout(th, tw, lv.k_tiles);
+    DetectLds L;
+    L.img_stride = DET_S; L.img_rows = lv.det_img_rows; L.score_w = lv.det_score_w; L.score_rows = lv.det_score_rows; L.list_cap = lv.det_list_cap;
+    L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
     unsigned char *s_img = smem;
     unsigned short *s_score = reinterpret_cast<unsigned short *>(smem + L.off_score);
     unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
 
     int pitch;
-    const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
+    const uint8_t *img = level_ptr_uniform(g, src, slab, b, lvl, lv.pitch, lv.img_off, pitch);
 
     // ---- phase 0: stage image rows [y0-4, y0+th+4) x cols [xs, xs+S) with 16-byte loads ; zero the score tile ----
     // (4-byte loads cap a CU at ~1/4 of its HBM rate: the vector-memory pipeline retires one wave-instruction per
