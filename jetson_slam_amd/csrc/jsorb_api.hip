@@ -228,11 +228,11 @@ int run_pipeline(jsorb_extractor *e, int n)
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->readers_done, 0));
         e->has_readers = false;
     }
-    TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, n, e->pyr_lds, e->stream));
+    TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, e->lut_bits, n, e->pyr_lds, e->stream));
     TIMED(e, JSORB_K_DETECT, launch_detect(g, e->src, e->slab, e->mask, e->lut_bits, e->tile_out, n, e->detect_lds, e->stream));
     if (e->nms_ms) TIMED(e, JSORB_K_NMS_MS, launch_nms_ms(g, e->tile_out, e->ms_grid, e->ms_scratch, e->p.nms_ms_mode_gpu, n, e->stream));
     TIMED(e, JSORB_K_COMPACT, launch_compact(g, e->tile_out, e->kp, e->counts, e->row_tab, n, e->stream));
-    TIMED(e, JSORB_K_BLUR, launch_blur(g, e->src, e->slab, e->blur, n, e->stream));
+    TIMED(e, JSORB_K_BLUR, launch_blur(g, e->src, e->slab, e->blur, e->lut_bits, n, e->stream));
     TIMED(e, JSORB_K_DESCRIBE, launch_describe(g, e->src, e->slab, e->blur, e->kp, e->counts, e->angles, e->desc, e->out_kp, n, e->stream));
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipMemcpyAsync(e->h_counts, e->counts, sizeof(int) * (JSORB_MAX_LEVELS + 1) * n, hipMemcpyDeviceToHost, e->stream));
@@ -295,7 +295,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
             HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k], hipEventDisableTiming));
         }
     }
-    HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks) * sizeof(uint32_t)));      // arc LUT + k_detect workgroup table
+    HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks) * sizeof(uint32_t)));      // arc LUT + workgroup tables
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
     HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
@@ -333,12 +333,23 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
                 const int m0 = j & 1, m4 = (j >> 4) & 1, m8 = (j >> 8) & 1, m12 = (j >> 12) & 1;
                 if (!((m0 | m8) & (m4 | m12))) g.lut_compass = 0;
             }
-        // k_detect workgroup table: level | tile row << 4 | tile group << 18
-        bits.resize(2048 + (size_t)g.detect_blocks);
-        for (int i = 0; i < g.L; i++)
-            for (int r = 0; r < g.lv[i].nth; r++)
-                for (int gr = 0; gr < g.lv[i].groups_per_row; gr++)
-                    bits[2048 + g.lv[i].detect_blk0 + r * g.lv[i].groups_per_row + gr] = (uint32_t)i | ((uint32_t)r << 4) | ((uint32_t)gr << 18);
+        // workgroup tables (jsorb_device.h, CTAB_*): level | tile row << 4 | tile column << 18
+        bits.resize(2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks);
+        int btw, bth;
+        blur_tile_dims(&btw, &bth);
+        for (int i = 0; i < g.L; i++) {
+            const LevelDesc &lv = g.lv[i];
+            for (int r = 0; r < lv.nth; r++)
+                for (int gr = 0; gr < lv.groups_per_row; gr++)
+                    bits[CTAB_DETECT + lv.detect_blk0 + r * lv.groups_per_row + gr] = (uint32_t)i | ((uint32_t)r << 4) | ((uint32_t)gr << 18);
+            for (int by = 0; by < lv.blur_by; by++)
+                for (int bx = 0; bx < lv.blur_bx; bx++)
+                    bits[ctab_blur(g) + lv.blur_blk0 + by * lv.blur_bx + bx] = (uint32_t)i | ((uint32_t)by << 4) | ((uint32_t)bx << 18);
+            if (i >= 1)
+                for (int by = 0; by < (lv.H + PYR_TH - 1) / PYR_TH; by++)
+                    for (int bx = 0; bx < lv.pyr_bx; bx++)
+                        bits[ctab_pyramid(g) + lv.pyr_blk0 + by * lv.pyr_bx + bx] = (uint32_t)i | ((uint32_t)by << 4) | ((uint32_t)bx << 18);
+        }
         HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (mask) {

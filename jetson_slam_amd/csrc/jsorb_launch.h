@@ -19,7 +19,7 @@ struct StereoArgs {
 size_t detect_lds_bytes(const Geometry &g);
 
 size_t pyramid_lds_bytes(const Geometry &g);
-void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, int n_images, size_t lds_bytes, hipStream_t s);
+void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, const uint32_t *ctab, int n_images, size_t lds_bytes, hipStream_t s);
 void fill_detect_layout(Geometry &g);      // per-level LDS layout of k_detect (host side, once per handle)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);
@@ -27,7 +27,7 @@ void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s);
 void blur_tile_dims(int *tw, int *th);     // k_blur's workgroup tile (host-side launch table)
-void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s);
+void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s);
 void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *blur_slab,
                      const unsigned long long *kp, const int *counts, float *angles, uint8_t *desc, int32_t *out_kp,
                      int n_images, hipStream_t s);

@@ -42,23 +42,23 @@ __constant__ unsigned c_gauss_bits[7][4] = {
 #define BLUR_STRIDE (BLUR_TW + 16)
 #define BLUR_HALF (BLUR_STRIP / 2)
 
-__global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, int n_images)
+__global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *__restrict__ ctab, int n_images)
 {
     __shared__ __align__(16) unsigned char tile[(BLUR_TH + 6) * BLUR_STRIDE];
     const int tid = threadIdx.x;
+    // workgroup-independent arguments in the first round of scalar loads, the workgroup descriptor (level, tile) in the second,
+    // the level in the third: the first image byte cannot be requested earlier (see k_detect)
+    asm volatile("" ::"s"(ctab), "s"(slab), "s"(blur_slab), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.detect_blocks));
     int b, blk;
     if (!xcd_map(blockIdx.x, g.blur_blocks, n_images, b, blk)) return;
-    int lvl = 0;
-#pragma unroll 1
-    for (int i = 1; i < g.L; i++)
-        if (blk >= g.lv[i].blur_blk0) lvl = i;
+    const unsigned wd = ctab_load(ctab, ctab_blur(g) + blk);
+    const int lvl = (int)(wd & 15u), by = (int)((wd >> 4) & 0x3FFFu), bx = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
-    const int lb = blk - lv.blur_blk0;
-    const int bx = lb % lv.blur_bx, by = lb / lv.blur_bx;
     const int H = lv.H, W = lv.W;
+    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(H), "s"(W));
     const int x0 = JSORB_BORDER + bx * BLUR_TW, y0 = JSORB_BORDER + by * BLUR_TH;
     int pitch;
-    const uint8_t *img = level_ptr(g, src, slab, b, lvl, pitch);
+    const uint8_t *img = level_ptr_uniform(g, src, slab, b, lvl, lv.pitch, lv.img_off, pitch);
 
     // 16-byte staging loads (x0 - 4 is a multiple of 16: x0 = 20 + BLUR_TW*bx)
     constexpr int NQ = BLUR_STRIDE / 16;
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
 
 void blur_tile_dims(int *tw, int *th) { *tw = BLUR_TW; *th = BLUR_TH; }
 
-void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, int n_images, hipStream_t s)
+void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s)
 {
     if (g.blur_blocks == 0) return;
-    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(g.blur_blocks, n_images)), dim3(256), 0, s, g, src, slab, blur_slab, n_images);
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(g.blur_blocks, n_images)), dim3(256), 0, s, g, src, slab, blur_slab, ctab, n_images);
 }
 
 } // namespace jsorb

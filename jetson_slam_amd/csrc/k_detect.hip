@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     if (!xcd_map(blockIdx.x, g.detect_blocks, n_images, b, blk)) return;
     // workgroup descriptor (level, tile row, tile group) from the host-built table behind the LUT: one scalar load instead of a
     // chain of dependent ones - the kernel is sensitive to the latency of this prologue (no vector work can start before it)
-    const unsigned wd = reinterpret_cast<const unsigned __attribute__((address_space(4))) *>(reinterpret_cast<size_t>(lut_bits))[2048 + blk];      // constant address space: s_load
+    const unsigned wd = ctab_load(lut_bits, CTAB_DETECT + blk);
     const int lvl = (int)(wd & 15u), r = (int)((wd >> 4) & 0x3FFFu), grp = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
     const int H = lv.H, W = lv.W, th = lv.th, tw = lv.tw;
