@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
                                                unsigned *__restrict__ aux, StereoArgs sa, int n_pairs)
 {
-    __shared__ int s_lvi[JSORB_MAX_LEVELS][8];       // th, nth, row_tab_off, W, pitch, img_off (per level, lane-indexable)
+    __shared__ int s_lvi[JSORB_MAX_LEVELS][8];       // th, nth, row_tab_off, W, pitch, img_off, 1/th magic (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
     const int lane = threadIdx.x;
     const int grp = lane / SGL, sl = lane % SGL;
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         const LevelDesc &lv = g.lv[lane];
         s_lvi[lane][0] = lv.th; s_lvi[lane][1] = lv.nth; s_lvi[lane][2] = lv.row_tab_off; s_lvi[lane][3] = lv.W;
         s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
+        s_lvi[lane][6] = (int)(0xFFFFFFFFu / (unsigned)lv.th + 1u);      // x / th == umulhi(x, magic) for x < 2^16, th > 1
         s_lvf[lane][0] = lv.scale; s_lvf[lane][1] = lv.inv_scale;
     }
     wave_lds_sync_st();
@@ -89,15 +90,17 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             const int lr = levelL - 1 + t;
             j0[t] = 0; len[t] = 0; rr[t] = 0.f;
             if (lr >= 0 && lr < g.L && !(maxU < 0)) {
-                const float scl = s_lvf[lr][0];
+                const float scl = s_lvf[lr][0], iscl = s_lvf[lr][1];
                 const int th = s_lvi[lr][0], nth = s_lvi[lr][1], rto = s_lvi[lr][2];
+                const unsigned th_magic = (unsigned)s_lvi[lr][6];
                 const float r = 2.0f * scl;
                 rr[t] = r;
-                // conservative tile-row window of level lr (exact tests follow per candidate)
-                const int lo = (int)__builtin_floorf((vL - r - 1.0f) / scl) - 1;
-                const int hi = (int)__builtin_ceilf((vL + r + 2.0f) / scl) + 1;
-                const int t_lo = lo < 0 ? 0 : lo / th;
-                int t_hi = hi < 0 ? -1 : hi / th;
+                // conservative tile-row window of level lr (exact tests follow per candidate): the product with 1/scale instead of
+                // the quotient moves the bounds by ~1e-4 px, the window carries a margin of a whole pixel on each side
+                const int lo = (int)__builtin_floorf((vL - r - 1.0f) * iscl) - 1;
+                const int hi = (int)__builtin_ceilf((vL + r + 2.0f) * iscl) + 1;
+                const int t_lo = lo < 0 ? 0 : (th > 1 ? (int)__umulhi((unsigned)lo, th_magic) : lo);
+                int t_hi = hi < 0 ? -1 : (th > 1 ? (int)__umulhi((unsigned)hi, th_magic) : hi);
                 if (t_hi > nth - 1) t_hi = nth - 1;
                 if (t_lo <= t_hi) {
                     j0[t] = rt[rto + t_lo];
