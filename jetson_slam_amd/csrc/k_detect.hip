@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 #pragma unroll
     for (int t = 0; t < 4; t++)
         if (q < nq && (unsigned)(cb + t - c_lo) < c_span) cm[t >> 1] |= (t & 1) ? 0x80000000u : 0x8000u;
-    // |p - v| <= th for two pixels per instruction (v_pk_sub_i16): with a = p - (v - th), "far" <=> a < 0 or 2*th - a < 0,
-    // i.e. the sign bit of (a | (2*th - a)) in each 16-bit half.  th >= 256 behaves like 256 (every pixel is "near").
+    // two pixels per instruction in the 16-bit halves of a dword (v_pk_*_i16); every test ends as the sign bit of a packed
+    // difference.  th >= 256 behaves like 256 (every pixel is "near").
     typedef short s2 __attribute__((ext_vector_type(2)));
     const int thc = min(threshold, 256);
-    const s2 th_pk = (s2){(short)thc, (short)thc}, th2_pk = (s2){(short)(2 * thc), (short)(2 * thc)};
+    const s2 th_pk = (s2){(short)thc, (short)thc};
 #define PK(hi, lo, sel) __builtin_bit_cast(s2, __builtin_amdgcn_perm((hi), (lo), (sel)))
     for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += 4 * rows_per_step) {
         const int ry = rbase + sub;
@@ -197,18 +197,24 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             const s2 p4 = h ? PK(0u, Dp, 0x0c020c01u) : PK(D0, Dp, 0x0c000c07u);       // x + 3
             const s2 p0 = PK(0u, Dd, h ? 0x0c030c02u : 0x0c010c00u);                   // y + 3
             const s2 p8 = PK(0u, Du, h ? 0x0c030c02u : 0x0c010c00u);                   // y - 3
-            const s2 vmt = v - th_pk;
-            const s2 a4 = p4 - vmt, a12 = p12 - vmt, a0 = p0 - vmt, a8 = p8 - vmt;
-            const s2 b4 = th2_pk - a4, b12 = th2_pk - a12, b0 = th2_pk - a0, b8 = th2_pk - a8;    // sign of a: darker, sign of b: brighter
+            // brighter(p) <=> p > v + th, darker(p) <=> p < v - th; an OR over two pixels is a max / min of the pair, an AND over the
+            // two pairs a min / max of those: 4 + 2 packed min/max and 2 packed subtractions (sign bits) instead of 16 subtractions
+            const s2 vpt = v + th_pk, vmt = v - th_pk;
+            const s2 mx_h = __builtin_elementwise_max(p4, p12), mn_h = __builtin_elementwise_min(p4, p12);
+            const s2 mx_v = __builtin_elementwise_max(p0, p8), mn_v = __builtin_elementwise_min(p0, p8);
             unsigned ok;
             if (COMPASS) {
                 // every mask the arc LUT accepts has two adjacent compass pixels of the same polarity (host-checked property of
-                // the LUT): a strict subset of the reference's early rejects that still contains every pixel with a positive score
-                ok = __builtin_bit_cast(unsigned, (s2)(((b4 | b12) & (b0 | b8)) | ((a4 | a12) & (a0 | a8))));
+                // the LUT): a strict subset of the reference's early rejects that still contains every pixel with a positive score.
+                // (B4|B12) & (B0|B8) <=> min(max(p4,p12), max(p0,p8)) > v + th ; (D4|D12) & (D0|D8) <=> max(min, min) < v - th
+                const s2 bright = vpt - __builtin_elementwise_min(mx_h, mx_v);
+                const s2 dark = __builtin_elementwise_max(mn_h, mn_v) - vmt;
+                ok = __builtin_bit_cast(unsigned, (s2)(bright | dark));
             } else {
-                const s2 far_h = a4 | b4 | a12 | b12;                                   // sign set: 4 or 12 is far from v
-                const s2 far_v = a0 | b0 | a8 | b8;
-                ok = __builtin_bit_cast(unsigned, (s2)(far_h & far_v));                // !((near4 && near12) || (near0 && near8))
+                // reference: !((near4 && near12) || (near0 && near8)), near(p) <=> |p - v| <= th
+                const s2 far_h = (vpt - mx_h) | (mn_h - vmt);                           // sign set: 4 or 12 is far from v
+                const s2 far_v = (vpt - mx_v) | (mn_v - vmt);
+                ok = __builtin_bit_cast(unsigned, (s2)(far_h & far_v));
             }
             okw[h] = ok & (row_ok ? cm[h] : 0u);
         }
