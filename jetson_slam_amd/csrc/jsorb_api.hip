@@ -115,6 +115,7 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
     for (int i = 0; i < g.L; i++) {
         LevelDesc &lv = g.lv[i];
         lv.scale = scale[i]; lv.inv_scale = inv[i];
+        lv.pyr_s = 1.0f / inv[i];
         lv.pitch = round_up(lv.W, 64);
         lv.img_off = off;
         off += (unsigned long long)lv.pitch * lv.H;
