@@ -1,10 +1,12 @@
 // stereo_frame.cpp - the Frame stereo constructor's front-end half (Frame.cpp:80-250) written against the compat shim:
 // two ORBExtractor objects run from two std::threads, SyncedMem::to_cpu(), SoA unpack, ComputeStereoMatches.
 // Usage: stereo_frame H W L tile th fx bf left.raw right.raw out.bin
-// out.bin: int32 N_l, N_r, then kp_l[6N_l] desc_l[32N_l] kp_r[6N_r] desc_r[32N_r] uRight[N_l] depth[N_l]
+// out.bin: int32 N_l, N_r, then kp_l[6N_l] desc_l[32N_l] kp_r[6N_r] desc_r[32N_r] uRight[N_l] depth[N_l],
+//          then mvKeys (N_l cv::KeyPoint-shaped records, 28 B each), then mGrid of the left image: 64*48 x { int32 count, int32 items[count] }
 // Build: g++ -std=c++17 -I include examples/stereo_frame.cpp -L jetson_slam_amd -ljsorb -lpthread
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -42,6 +44,21 @@ int main(int argc, char **argv)
         fwrite(kpL.cpu_data(), 4, 6 * (size_t)nl, f); fwrite(dL.cpu_data(), 1, 32 * (size_t)nl, f);
         fwrite(kpR.cpu_data(), 4, 6 * (size_t)nr, f); fwrite(dR.cpu_data(), 1, 32 * (size_t)nr, f);
         fwrite(mvuRight.data(), 4, nl, f); fwrite(mvDepth.data(), 4, nl, f);
+        // Frame.cpp:119-196 (unpack) and :463-479 (AssignFeaturesToGrid) through the device-side helpers
+        std::vector<jsorb_keypoint> mvKeys;
+        std::vector<unsigned char> mDescriptors;
+        Jetson_SLAM::UnpackFrame(exL, mvKeys, mDescriptors);
+        static std::vector<std::size_t> mGrid[64][48];                   // Frame.h:46-47,191
+        const float mnMinX = 0.0f, mnMinY = 0.0f, mnMaxX = (float)W, mnMaxY = (float)H;           // Frame.cpp:226-235, no distortion
+        Jetson_SLAM::AssignFeaturesToGrid(exL, mnMinX, mnMinY, 64.0f / (mnMaxX - mnMinX), 48.0f / (mnMaxY - mnMinY), mGrid);
+        fwrite(mvKeys.data(), sizeof(jsorb_keypoint), mvKeys.size(), f);
+        for (int i = 0; i < 64; i++)
+            for (int j = 0; j < 48; j++) {
+                const int cnt = (int)mGrid[i][j].size();
+                fwrite(&cnt, 4, 1, f);
+                for (std::size_t v : mGrid[i][j]) { const int iv = (int)v; fwrite(&iv, 4, 1, f); }
+            }
+        if (mDescriptors.size() != 32 * (size_t)nl || memcmp(mDescriptors.data(), dL.cpu_data(), mDescriptors.size()) != 0) { fprintf(stderr, "UnpackFrame descriptors differ\n"); return 3; }
         fclose(f);
         int matched = 0;
         for (float d : mvDepth) matched += d > 0;

@@ -138,6 +138,20 @@ int jsorb_is_in_frustum(void *hip_stream, int n_points, const float *Px, const f
                         int maxY, int nScaleLevels, float logScaleFactor, float viewCosAngle, float *invz, float *u, float *v, int *predictedlevel,
                         float *viewCos, unsigned char *is_infrustum);
 
+/* ---- Frame-side unpacking: what Frame::Frame does on the host right after the two extract() calls ---- */
+/* The memory layout of cv::KeyPoint (OpenCV 4: Point2f pt; float size, angle, response; int octave, class_id), 28 bytes. */
+typedef struct jsorb_keypoint { float x, y, size, angle, response; int32_t octave, class_id; } jsorb_keypoint;
+/* Frame.cpp:119-196: the keypoint SoA of one image of the last batch as cv::KeyPoint records + its descriptor rows (N x 32).
+ * A device kernel interleaves the SoA; both arrays then come back with two asynchronous copies and ONE synchronisation (the
+ * reference: four blocking SyncedMem::to_cpu() per stereo frame, then a host loop).  Either destination may be NULL. */
+int jsorb_unpack_frame(jsorb_extractor *e, int image, jsorb_keypoint *keypoints, uint8_t *descriptors);
+/* Frame::AssignFeaturesToGrid + Frame::PosInGrid (Frame.cpp:463-479, 696-706) on the device, as CSR over cols x rows cells:
+ * cell (i, j) has index i*rows + j (mGrid[i][j]); cell_start has cols*rows + 1 entries; cell_items lists keypoint indices,
+ * ascending inside a cell (the reference's push_back order).  Uses the extracted keypoint coordinates (mvKeysUn == mvKeys for
+ * rectified stereo).  Host destinations; cols*rows <= 16384. */
+int jsorb_assign_features_to_grid(jsorb_extractor *e, int image, float min_x, float min_y, float grid_element_width_inv,
+                                  float grid_element_height_inv, int cols, int rows, int32_t *cell_start, int32_t *cell_items);
+
 /* ---- plumbing ---- */
 /* Use an external HIP stream (hipStream_t as void*) instead of the handle's own, e.g. torch's current stream. NULL restores. */
 int jsorb_set_stream(jsorb_extractor *e, void *hip_stream);

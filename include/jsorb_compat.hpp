@@ -146,6 +146,50 @@ inline void ComputeStereoMatches(ORBExtractor &left, ORBExtractor &right, float 
     if (rc != JSORB_OK) throw std::runtime_error(std::string("jsorb_stereo_match: ") + jsorb_last_error(left.orb_gpu_));
 }
 
+// Body of the keypoint / descriptor unpacking of Frame::Frame (Frame.cpp:119-196) for one image: mvKeys-shaped records (the
+// memory layout of cv::KeyPoint) and the N x 32 descriptor rows, produced on the device and fetched with one synchronisation
+// instead of SyncedMem::to_cpu() x 2 + a host loop.
+inline void UnpackFrame(ORBExtractor &ex, std::vector<jsorb_keypoint> &keys, std::vector<unsigned char> &descriptors)
+{
+    const int n = jsorb_n_keypoints(ex.orb_gpu_, 0);
+    if (n < 0) throw std::runtime_error("UnpackFrame before extract");
+    keys.resize(n);
+    descriptors.resize((size_t)32 * n);
+    if (n && jsorb_unpack_frame(ex.orb_gpu_, 0, keys.data(), descriptors.data()) != JSORB_OK)
+        throw std::runtime_error(std::string("jsorb_unpack_frame: ") + jsorb_last_error(ex.orb_gpu_));
+}
+#ifdef JSORB_WITH_OPENCV
+inline void UnpackFrame(ORBExtractor &ex, std::vector<cv::KeyPoint> &mvKeys, cv::Mat &mDescriptors)
+{
+    static_assert(sizeof(cv::KeyPoint) == sizeof(jsorb_keypoint), "jsorb_keypoint mirrors cv::KeyPoint");
+    const int n = jsorb_n_keypoints(ex.orb_gpu_, 0);
+    if (n < 0) throw std::runtime_error("UnpackFrame before extract");
+    mvKeys.resize(n);
+    mDescriptors = cv::Mat(n, 32, CV_8UC1);
+    if (n && jsorb_unpack_frame(ex.orb_gpu_, 0, reinterpret_cast<jsorb_keypoint *>(mvKeys.data()), mDescriptors.data) != JSORB_OK)
+        throw std::runtime_error(std::string("jsorb_unpack_frame: ") + jsorb_last_error(ex.orb_gpu_));
+}
+#endif
+
+// Body of Frame::AssignFeaturesToGrid (Frame.cpp:463-479) for the extracted keypoints (mvKeysUn == mvKeys, rectified stereo):
+// mGrid is the reference's std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS] (Frame.h:191).
+template <std::size_t COLS, std::size_t ROWS>
+inline void AssignFeaturesToGrid(ORBExtractor &ex, float mnMinX, float mnMinY, float mfGridElementWidthInv, float mfGridElementHeightInv,
+                                 std::vector<std::size_t> (&mGrid)[COLS][ROWS])
+{
+    const int n = jsorb_n_keypoints(ex.orb_gpu_, 0);
+    if (n < 0) throw std::runtime_error("AssignFeaturesToGrid before extract");
+    std::vector<int32_t> start(COLS * ROWS + 1), items(n > 0 ? n : 1);
+    if (jsorb_assign_features_to_grid(ex.orb_gpu_, 0, mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv, (int)COLS, (int)ROWS,
+                                      start.data(), items.data()) != JSORB_OK)
+        throw std::runtime_error(std::string("jsorb_assign_features_to_grid: ") + jsorb_last_error(ex.orb_gpu_));
+    for (std::size_t i = 0; i < COLS; i++)
+        for (std::size_t j = 0; j < ROWS; j++) {
+            const std::size_t c = i * ROWS + j;
+            mGrid[i][j].assign(items.begin() + start[c], items.begin() + start[c + 1]);
+        }
+}
+
 } // namespace Jetson_SLAM
 
 #endif // JSORB_COMPAT_HPP

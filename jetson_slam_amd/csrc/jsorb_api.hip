@@ -59,6 +59,10 @@ struct jsorb_extractor {
     float *st_u = nullptr, *st_d = nullptr;
     int *st_l1 = nullptr, *st_stats = nullptr;
     unsigned *st_aux = nullptr;
+    // Frame-side unpacking (allocated on first use, then kept): AoS keypoints of one image, grid CSR
+    jsorb_keypoint *frame_aos = nullptr;
+    int32_t *grid_start = nullptr, *grid_items = nullptr;
+    int grid_cells = 0;
     bool nms_ms = false;
     int *ms_grid = nullptr, *ms_scratch = nullptr;   // NMS-MS: level-0 accumulator plane (GPU mode) / mutable scores (CPU mode)
     // pinned host mirrors
@@ -383,7 +387,7 @@ void jsorb_destroy(jsorb_extractor *e)
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
@@ -537,6 +541,48 @@ int jsorb_copy_descriptors(const jsorb_extractor *e, int image, uint8_t *dst)
     const int n = jsorb_n_keypoints(e, image);
     if (n <= 0) return JSORB_OK;
     return hipMemcpy(dst, jsorb_descriptors_device(e, image), (size_t)n * 32, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
+
+// ---- Frame-side unpacking ----
+int jsorb_unpack_frame(jsorb_extractor *e, int image, jsorb_keypoint *keypoints, uint8_t *descriptors)
+{
+    if (!check_image(e, image)) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(e, image);
+    if (n <= 0) return JSORB_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (keypoints) {
+        if (!e->frame_aos) HIPCHK(e, hipMalloc(&e->frame_aos, (size_t)e->g.T * sizeof(jsorb_keypoint)));
+        launch_unpack_keypoints(jsorb_keypoints_device(e, image), n, e->frame_aos, e->stream);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipMemcpyAsync(keypoints, e->frame_aos, (size_t)n * sizeof(jsorb_keypoint), hipMemcpyDeviceToHost, e->stream));
+    }
+    if (descriptors) HIPCHK(e, hipMemcpyAsync(descriptors, jsorb_descriptors_device(e, image), (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return JSORB_OK;
+}
+
+int jsorb_assign_features_to_grid(jsorb_extractor *e, int image, float min_x, float min_y, float grid_element_width_inv,
+                                  float grid_element_height_inv, int cols, int rows, int32_t *cell_start, int32_t *cell_items)
+{
+    if (!check_image(e, image) || !cell_start || !cell_items) return JSORB_ERR_STATE;
+    if (cols < 1 || rows < 1 || (long long)cols * rows > 16384) { e->err = "grid size out of range (cols*rows <= 16384)"; return JSORB_ERR_INVALID; }
+    const int n = jsorb_n_keypoints(e, image), n_cells = cols * rows;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->grid_cells < n_cells) {
+        if (e->grid_start) (void)hipFree(e->grid_start);
+        e->grid_start = nullptr;
+        HIPCHK(e, hipMalloc(&e->grid_start, (size_t)(n_cells + 1) * sizeof(int32_t)));
+        e->grid_cells = n_cells;
+    }
+    if (!e->grid_items) HIPCHK(e, hipMalloc(&e->grid_items, (size_t)e->g.T * sizeof(int32_t)));
+    launch_assign_grid(jsorb_keypoints_device(e, image), n, min_x, min_y, grid_element_width_inv, grid_element_height_inv, cols, rows,
+                       e->grid_start, e->grid_items, e->stream);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(cell_start, e->grid_start, (size_t)(n_cells + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const int in_grid = cell_start[n_cells];
+    if (in_grid > 0) HIPCHK(e, hipMemcpy(cell_items, e->grid_items, (size_t)in_grid * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return JSORB_OK;
 }
 
 int jsorb_n_levels(const jsorb_extractor *e) { return e ? e->g.L : 0; }

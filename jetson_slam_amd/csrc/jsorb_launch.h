@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/jsorb.h"
 #include "jsorb_device.h"
 
 namespace jsorb {
@@ -35,6 +36,9 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
                    float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s);
+void launch_unpack_keypoints(const int32_t *soa, int n, jsorb_keypoint *out, hipStream_t s);
+void launch_assign_grid(const int32_t *soa, int n, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
+                        int32_t *cell_start, int32_t *cell_items, hipStream_t s);
 void launch_gather_counts(const int *countsL, const int *countsR, const int *stats, int32_t *dst, int n_pairs, hipStream_t s);
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
                    int *stats, int n_pairs, hipStream_t s);

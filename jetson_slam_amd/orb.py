@@ -30,7 +30,12 @@ EXPORTS = [
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
     "jsorb_copy_stereo", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
     "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
+    "jsorb_unpack_frame", "jsorb_assign_features_to_grid",
 ]
+
+
+# memory layout of cv::KeyPoint (jsorb_keypoint in include/jsorb.h)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 
 
 class JsorbParams(C.Structure):
@@ -105,6 +110,8 @@ def load_library(path=None):
         "jsorb_project_points": (I, [P, I] + [P] * 5 + [F] * 8 + [P] * 4),
         "jsorb_hamming_pairs": (I, [P, I] + [P] * 5),
         "jsorb_is_in_frustum": (I, [P, I] + [P] * 12 + [F] * 4 + [I] * 5 + [F] * 2 + [P] * 6),
+        "jsorb_unpack_frame": (I, [P, I, P, P]),
+        "jsorb_assign_features_to_grid": (I, [P, I] + [F] * 4 + [I] * 2 + [P] * 2),
     }
     for name, (rt, at) in sig.items():
         fn = getattr(lib, name)
@@ -239,6 +246,28 @@ class ORBExtractor:
         if n:
             self._chk(self._lib.jsorb_copy_descriptors(self._h, image, out.ctypes.data))
         return out
+
+    def unpack_frame(self, image=0):
+        """Frame.cpp:119-196 on the device: (keypoints as a structured array with the layout of cv::KeyPoint, descriptors N x 32)."""
+        n = self.n_keypoints(image)
+        if n < 0:
+            raise JsorbError("no extract result for image %d" % image)
+        kps = np.zeros(n, KEYPOINT_DTYPE)
+        desc = np.zeros((n, 32), np.uint8)
+        if n:
+            self._chk(self._lib.jsorb_unpack_frame(self._h, image, kps.ctypes.data, desc.ctypes.data))
+        return kps, desc
+
+    def assign_features_to_grid(self, min_x, min_y, grid_element_width_inv, grid_element_height_inv, cols=64, rows=48, image=0):
+        """Frame::AssignFeaturesToGrid (Frame.cpp:463-479) as CSR: (cell_start[cols*rows+1], cell_items); cell (i, j) = i*rows + j."""
+        n = self.n_keypoints(image)
+        if n < 0:
+            raise JsorbError("no extract result for image %d" % image)
+        start = np.zeros(cols * rows + 1, np.int32)
+        items = np.zeros(max(n, 1), np.int32)
+        self._chk(self._lib.jsorb_assign_features_to_grid(self._h, image, min_x, min_y, grid_element_width_inv, grid_element_height_inv,
+                                                          cols, rows, start.ctypes.data, items.ctypes.data))
+        return start, items[:start[-1]]
 
     def angles(self, image=0):
         n = self.n_keypoints(image)

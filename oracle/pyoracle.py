@@ -68,6 +68,8 @@ def _load(native=False):
         "orc_project_points": (None, [C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 8 + [C.c_void_p] * 4),
         "orc_hamming_pairs": (None, [C.c_int] + [C.c_void_p] * 5),
         "orc_logf": (C.c_float, [C.c_float]),
+        "orc_unpack_keypoints": (None, [C.c_int, C.c_void_p, C.c_void_p]),
+        "orc_assign_features_to_grid": (C.c_int, [C.c_int, C.c_void_p] + [C.c_float] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2),
         "orc_is_in_frustum": (None, [C.c_int] + [C.c_void_p] * 12 + [C.c_float] * 4 + [C.c_int] * 5 + [C.c_float] * 2 + [C.c_void_p] * 6),
         "orc_bench_pairs": (C.c_long, [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double,
                                       C.c_int, C.POINTER(C.c_double)]),
@@ -219,3 +221,25 @@ def bench_pairs(lefts, rights, mb, mbf, seconds, n_threads, native=True, **kw):
     el = C.c_double()
     n = l.orc_bench_pairs(C.byref(p), lefts.ctypes.data, rights.ctypes.data, lefts.shape[0], mb, mbf, seconds, n_threads, C.byref(el))
     return n, el.value
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def unpack_keypoints(soa, native=False):
+    """Frame.cpp:119-196: keypoint SoA (6N int32) -> structured array with the memory layout of cv::KeyPoint."""
+    soa = np.ascontiguousarray(soa, np.int32)
+    n = soa.size // 6
+    out = np.zeros(n, KEYPOINT_DTYPE)
+    lib(native).orc_unpack_keypoints(n, soa.ctypes.data, out.ctypes.data)
+    return out
+
+
+def assign_features_to_grid(soa, min_x, min_y, inv_w, inv_h, cols=64, rows=48, native=False):
+    """Frame::AssignFeaturesToGrid (Frame.cpp:463-479): (cell_start[cols*rows+1], cell_items[n_in_grid])."""
+    soa = np.ascontiguousarray(soa, np.int32)
+    n = soa.size // 6
+    start = np.zeros(cols * rows + 1, np.int32)
+    items = np.zeros(max(n, 1), np.int32)
+    k = lib(native).orc_assign_features_to_grid(n, soa.ctypes.data, min_x, min_y, inv_w, inv_h, cols, rows, start.ctypes.data, items.ctypes.data)
+    return start, items[:k]
