@@ -80,7 +80,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
-    ap.add_argument("--single-stream", action="store_true", help="left and right handles share one HIP stream (clean per-kernel times)")
+    ap.add_argument("--single-stream", action="store_true", help="all handles share one HIP stream (clean per-kernel times)")
+    ap.add_argument("--groups", type=int, default=2, help="the step's pairs are split over this many independent left/right handle pairs "
+                    "(2 streams each): kernels of different stages then overlap on the GPU (+5-7 %% over one pair of handles)")
     args = ap.parse_args()
 
     import torch
@@ -110,32 +112,39 @@ def main():
     left_d = torch.from_numpy(left_h).to(dev)
     right_d = torch.from_numpy(right_h).to(dev)
 
-    mk = lambda: orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, device_id=local_rank, max_batch=P)
-    exl, exr = mk(), mk()
+    G = args.groups if args.groups >= 1 and P % max(1, args.groups) == 0 else 1
+    per = P // G                                  # pairs per handle pair and launch
+    mk = lambda: orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, device_id=local_rank, max_batch=per)
+    groups = [(mk(), mk()) for _ in range(G)]
+    exl, exr = groups[0]
+    handles = [h for pair in groups for h in pair]
     # each handle keeps its own HIP stream: left and right extraction overlap (the reference runs them in two host threads),
-    # the stereo kernel on the left stream waits for the right stream's event.
+    # the stereo kernel on the left stream waits for the right stream's event; the G handle pairs are independent of each other.
     torch_stream_ptr = torch.cuda.current_stream(dev).cuda_stream
     shared_stream = None
     if args.single_stream:
         shared_stream = torch.cuda.Stream(dev)
-        exl.set_stream(shared_stream.cuda_stream)
-        exr.set_stream(shared_stream.cuda_stream)
+        for h in handles:
+            h.set_stream(shared_stream.cuda_stream)
     counts_d = torch.zeros(P * 3, dtype=torch.int32, device=dev)
     gathered = [torch.zeros_like(counts_d) for _ in range(world)] if world > 1 else None
     mb = bf / fx
 
     def step():
-        exl.extract_batch_device_async(left_d.data_ptr(), H * W, W, P, keep=left_d)
-        exr.extract_batch_device_async(right_d.data_ptr(), H * W, W, P, keep=right_d)
-        orb.stereo_match_batch_async(exl, exr, mb, bf)
+        for gi, (a, b) in enumerate(groups):
+            a.extract_batch_device_async(left_d[gi * per:].data_ptr(), H * W, W, per, keep=left_d)
+            b.extract_batch_device_async(right_d[gi * per:].data_ptr(), H * W, W, per, keep=right_d)
+        for a, b in groups:
+            orb.stereo_match_batch_async(a, b, mb, bf)
         if world > 1:   # the one collective of the path: per-pair (N_left, N_right, N_matched), <1 KB per rank
-            orb.gather_counts_async(exl, exr, counts_d.data_ptr())
-            exl.stream_wait_done(torch_stream_ptr)      # RCCL is issued from torch's stream: order it after the left stream
+            for gi, (a, b) in enumerate(groups):
+                orb.gather_counts_async(a, b, counts_d[gi * per * 3:].data_ptr())
+                a.stream_wait_done(torch_stream_ptr)    # RCCL is issued from torch's stream: order it after the left streams
             dist.all_gather(gathered, counts_d)
 
     def fence():
-        exl.sync()
-        exr.sync()
+        for h in handles:
+            h.sync()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -176,16 +185,16 @@ def main():
     # other handle's kernels (the timed region above overlaps left and right on two streams)
     if shared_stream is None:
         shared_stream = torch.cuda.Stream(dev)
-        exl.set_stream(shared_stream.cuda_stream)
-        exr.set_stream(shared_stream.cuda_stream)
-    for e in (exl, exr):
+        for h in handles:
+            h.set_stream(shared_stream.cuda_stream)
+    for e in handles:
         e.reset_kernel_timing()
         e.enable_kernel_timing(True)
     for _ in range(args.profile_steps):
         step()
     fence()
     kt = {}
-    for e in (exl, exr):
+    for e in handles:
         for k, (ms, n) in e.kernel_times().items():
             a = kt.setdefault(k, [0.0, 0])
             a[0] += ms
@@ -197,8 +206,8 @@ def main():
         per_step_ms = {k: v[0] / max(1, args.profile_steps) for k, v in kt.items()}
         dom = max(per_step_ms, key=per_step_ms.get)
         avg_ms = kt[dom][0] / max(1, kt[dom][1])
-        # one launch of an extract-side kernel covers P images = P/2 stereo pairs; a stereo-side launch covers P pairs
-        units = P if dom in ("k_stereo", "k_median") else P / 2.0
+        # one launch of an extract-side kernel covers `per` images = per/2 stereo pairs; a stereo-side launch covers `per` pairs
+        units = per if dom in ("k_stereo", "k_median") else per / 2.0
         achieved = ab * units / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -223,7 +232,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "EuRoC-shaped %dx%d stereo, %d levels, scale 1.2, tile %d (cap %d kp/image), th_FAST %d, N[9,14]"
                                    % (W, H, L, tile, T, th) if args.config == "c2" else args.config,
-                       "name": args.config, "pairs_per_gpu_per_step": P, "keypoints_image0": n0, "inputs": "device-resident u8",
+                       "name": args.config, "pairs_per_gpu_per_step": P, "handle_pairs": G, "pairs_per_launch": per, "keypoints_image0": n0,
+                       "inputs": "device-resident u8",
                        "parallelism": "independent pairs sharded over %d GPU(s); RCCL all_gather of counts only" % world},
             "parity_vs_oracle": parity, "roofline": roof, "cpu_baseline": cpu,
         }
