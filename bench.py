@@ -81,8 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
     ap.add_argument("--single-stream", action="store_true", help="all handles share one HIP stream (clean per-kernel times)")
-    ap.add_argument("--groups", type=int, default=2, help="the step's pairs are split over this many independent left/right handle pairs "
-                    "(2 streams each): kernels of different stages then overlap on the GPU (+5-7 %% over one pair of handles)")
+    ap.add_argument("--groups", type=int, default=4, help="the step's pairs are split over this many independent left/right handle pairs, "
+                    "one HIP stream per pair: kernels of different stages then overlap on the GPU (+6-8 %% over one pair of handles)")
     args = ap.parse_args()
 
     import torch
@@ -118,14 +118,21 @@ def main():
     groups = [(mk(), mk()) for _ in range(G)]
     exl, exr = groups[0]
     handles = [h for pair in groups for h in pair]
-    # each handle keeps its own HIP stream: left and right extraction overlap (the reference runs them in two host threads),
-    # the stereo kernel on the left stream waits for the right stream's event; the G handle pairs are independent of each other.
+    # The G handle pairs are independent of each other and run on G HIP streams (left and right of a pair share one): while one
+    # pair is in its latency-bound stages (FAST ring test / NMS, descriptor gathers) another one is in a streaming stage.
     torch_stream_ptr = torch.cuda.current_stream(dev).cuda_stream
     shared_stream = None
+    group_streams = []
     if args.single_stream:
         shared_stream = torch.cuda.Stream(dev)
         for h in handles:
             h.set_stream(shared_stream.cuda_stream)
+    elif G > 1:
+        for a, b in groups:
+            st = torch.cuda.Stream(dev)
+            group_streams.append(st)
+            a.set_stream(st.cuda_stream)
+            b.set_stream(st.cuda_stream)
     counts_d = torch.zeros(P * 3, dtype=torch.int32, device=dev)
     gathered = [torch.zeros_like(counts_d) for _ in range(world)] if world > 1 else None
     mb = bf / fx

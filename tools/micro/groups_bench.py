@@ -13,6 +13,11 @@ right = torch.from_numpy(np.stack([pairs[i % 16][1] for i in range(P)])).cuda()
 for G in [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '1,2,4,8'.split(','))]:
     per = P // G
     hs = [(orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, max_batch=per), orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, max_batch=per)) for _ in range(G)]
+    if len(sys.argv) > 3 and sys.argv[3] == 'shared':
+        keep = []
+        for a, b in hs:
+            st = torch.cuda.Stream(); keep.append(st)
+            a.set_stream(st.cuda_stream); b.set_stream(st.cuda_stream)
     def step():
         for gi, (a, b) in enumerate(hs):
             a.extract_batch_device_async(left[gi * per:].data_ptr(), H * W, W, per)
