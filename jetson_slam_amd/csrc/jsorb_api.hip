@@ -67,6 +67,13 @@ struct jsorb_extractor {
     int *ms_grid = nullptr, *ms_scratch = nullptr;   // NMS-MS: level-0 accumulator plane (GPU mode) / mutable scores (CPU mode)
     // pinned host mirrors
     int *h_counts = nullptr, *h_stats = nullptr;
+    // single-frame synchronous calls (the reference's call shape): results are mirrored into pinned memory speculatively, in the
+    // same stream round trip as the counts, so that SyncedMem::to_cpu() / the stereo outputs cost a memcpy instead of a blocking D2H
+    int32_t *h_kp = nullptr;
+    uint8_t *h_desc = nullptr;
+    float *h_u = nullptr, *h_d = nullptr;
+    int spec_cap = 0;          // keypoints covered by the speculative copy (tracks the previous frame's count)
+    bool mirror_valid = false, st_mirror_valid = false;
     ImageSrc src{};            // where level 0 of the last extract lives
     bool extracted = false, stereo_done = false;
     int stereo_pairs = 0;
@@ -327,6 +334,11 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipHostMalloc(&e->h_counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
     HIPCHK(e, hipHostMalloc(&e->h_stats, B * 8 * sizeof(int)));
     memset(e->h_counts, 0, B * (JSORB_MAX_LEVELS + 1) * sizeof(int));
+    HIPCHK(e, hipHostMalloc(&e->h_kp, T * 6 * sizeof(int32_t)));
+    HIPCHK(e, hipHostMalloc(&e->h_desc, T * 32));
+    HIPCHK(e, hipHostMalloc(&e->h_u, T * sizeof(float)));
+    HIPCHK(e, hipHostMalloc(&e->h_d, T * sizeof(float)));
+    e->spec_cap = (int)std::min<size_t>(T, 4096);
     {
         std::vector<uint32_t> bits;
         build_lut_bits(params->fast_n_min, params->fast_n_max, bits);
@@ -391,6 +403,8 @@ void jsorb_destroy(jsorb_extractor *e)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
+    for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d})
+        if (hp) (void)hipHostFree(hp);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->done) (void)hipEventDestroy(e->done);
     if (e->readers_done) (void)hipEventDestroy(e->readers_done);
@@ -430,6 +444,7 @@ int jsorb_sync(jsorb_extractor *e)
 int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
 {
     if (!e || !host_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
+    e->mirror_valid = e->st_mirror_valid = false;
     HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
     const size_t img_bytes = (size_t)l0.H * l0.W;
@@ -475,6 +490,7 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
 int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)
 {
     if (!e || !dev_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
+    e->mirror_valid = e->st_mirror_valid = false;
     HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
     const bool in_place = (step % 16 == 0) && (((uintptr_t)dev_images) % 16 == 0) && (image_stride % 16 == 0);   // kernels stage with 16-byte loads
@@ -490,24 +506,38 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     return run_pipeline(e, n_images);
 }
 
+// Tail of the synchronous single-frame calls: speculative D2H of the first spec_cap keypoints / descriptors into the pinned
+// mirrors, ONE stream synchronisation for counts + results, remainder fetched only if this frame has more keypoints than guessed.
+static int finish_single_frame(jsorb_extractor *e, int *n_keypoints)
+{
+    const int cap = e->spec_cap;
+    HIPCHK(e, hipMemcpyAsync(e->h_kp, e->out_kp, (size_t)cap * 6 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h_desc, e->desc, (size_t)cap * 32, hipMemcpyDeviceToHost, e->stream));
+    int rc = jsorb_sync(e);
+    if (rc) return rc;
+    const int n = e->h_counts[JSORB_MAX_LEVELS];
+    if (6 * (size_t)n > 6 * (size_t)cap) {        // the SoA is 6n contiguous ints: the prefix is in place, fetch the rest
+        HIPCHK(e, hipMemcpy(e->h_kp + (size_t)cap * 6, e->out_kp + (size_t)cap * 6, ((size_t)n - cap) * 6 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(e->h_desc + (size_t)cap * 32, e->desc + (size_t)cap * 32, ((size_t)n - cap) * 32, hipMemcpyDeviceToHost));
+    }
+    e->mirror_valid = true;
+    e->spec_cap = std::min(e->g.T, n + n / 4 + 256);
+    if (n_keypoints) *n_keypoints = n;
+    return JSORB_OK;
+}
+
 int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints)
 {
     int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
     if (rc) return rc;
-    rc = jsorb_sync(e);
-    if (rc) return rc;
-    if (n_keypoints) *n_keypoints = e->h_counts[JSORB_MAX_LEVELS];
-    return JSORB_OK;
+    return finish_single_frame(e, n_keypoints);
 }
 
 int jsorb_extract_device(jsorb_extractor *e, const uint8_t *dev_image, int step, int *n_keypoints)
 {
     int rc = jsorb_extract_batch_device_async(e, dev_image, 0, step, 1);
     if (rc) return rc;
-    rc = jsorb_sync(e);
-    if (rc) return rc;
-    if (n_keypoints) *n_keypoints = e->h_counts[JSORB_MAX_LEVELS];
-    return JSORB_OK;
+    return finish_single_frame(e, n_keypoints);
 }
 
 int jsorb_n_images(const jsorb_extractor *e) { return e ? e->n_images : 0; }
@@ -533,6 +563,7 @@ int jsorb_copy_keypoints(const jsorb_extractor *e, int image, int32_t *dst)
     if (!check_image(e, image) || !dst) return JSORB_ERR_STATE;
     const int n = jsorb_n_keypoints(e, image);
     if (n <= 0) return JSORB_OK;
+    if (e->mirror_valid && image == 0) { memcpy(dst, e->h_kp, (size_t)n * 6 * 4); return JSORB_OK; }
     return hipMemcpy(dst, jsorb_keypoints_device(e, image), (size_t)n * 6 * 4, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
 }
 int jsorb_copy_descriptors(const jsorb_extractor *e, int image, uint8_t *dst)
@@ -540,6 +571,7 @@ int jsorb_copy_descriptors(const jsorb_extractor *e, int image, uint8_t *dst)
     if (!check_image(e, image) || !dst) return JSORB_ERR_STATE;
     const int n = jsorb_n_keypoints(e, image);
     if (n <= 0) return JSORB_OK;
+    if (e->mirror_valid && image == 0) { memcpy(dst, e->h_desc, (size_t)n * 32); return JSORB_OK; }
     return hipMemcpy(dst, jsorb_descriptors_device(e, image), (size_t)n * 32, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
 }
 
@@ -549,6 +581,21 @@ int jsorb_unpack_frame(jsorb_extractor *e, int image, jsorb_keypoint *keypoints,
     if (!check_image(e, image)) return JSORB_ERR_STATE;
     const int n = jsorb_n_keypoints(e, image);
     if (n <= 0) return JSORB_OK;
+    if (e->mirror_valid && image == 0) {
+        // after a synchronous single-frame extract the SoA already sits in pinned host memory: interleave it here (the
+        // reference's own host loop, Frame.cpp:139-147) instead of a kernel + two copies + a synchronisation
+        if (keypoints) {
+            const int32_t *s = e->h_kp;
+            for (int i = 0; i < n; i++) {
+                jsorb_keypoint &k = keypoints[i];
+                k.x = (float)s[i]; k.y = (float)s[n + i]; k.response = (float)s[2 * (size_t)n + i];
+                memcpy(&k.angle, &s[3 * (size_t)n + i], 4);
+                k.octave = s[4 * (size_t)n + i]; k.size = (float)s[5 * (size_t)n + i]; k.class_id = -1;
+            }
+        }
+        if (descriptors) memcpy(descriptors, e->h_desc, (size_t)n * 32);
+        return JSORB_OK;
+    }
     HIPCHK(e, hipSetDevice(e->device));
     if (keypoints) {
         if (!e->frame_aos) HIPCHK(e, hipMalloc(&e->frame_aos, (size_t)e->g.T * sizeof(jsorb_keypoint)));
@@ -675,6 +722,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     if (l->last_stage >= 0) HIPCHK(l, hipEventRecord(l->ev_consumed[l->last_stage], l->stream));
     if (r->last_stage >= 0) HIPCHK(l, hipEventRecord(r->ev_consumed[r->last_stage], l->stream));
     l->stereo_done = true;
+    l->st_mirror_valid = false;
     l->stereo_pairs = n;
     return JSORB_OK;
 }
@@ -692,8 +740,13 @@ int jsorb_copy_stereo(const jsorb_extractor *l, int image, float *u_right, float
 {
     if (!check_image(l, image) || !l->stereo_done) return JSORB_ERR_STATE;
     const int n = jsorb_n_keypoints(l, image);
-    if (n > 0 && u_right && hipMemcpy(u_right, l->st_u + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
-    if (n > 0 && depth && hipMemcpy(depth, l->st_d + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
+    if (l->st_mirror_valid && image == 0) {
+        if (n > 0 && u_right) memcpy(u_right, l->h_u, (size_t)n * 4);
+        if (n > 0 && depth) memcpy(depth, l->h_d, (size_t)n * 4);
+    } else {
+        if (n > 0 && u_right && hipMemcpy(u_right, l->st_u + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
+        if (n > 0 && depth && hipMemcpy(depth, l->st_d + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return JSORB_ERR_HIP;
+    }
     if (stats) {
         const int *s = l->h_stats + image * 8;
         stats->n_left = n;
@@ -722,8 +775,14 @@ int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float m
 {
     int rc = jsorb_stereo_match_batch_async(l, r, mb, mbf, th_high, th_low);
     if (rc) return rc;
+    const int n = jsorb_n_keypoints(l, 0);
+    if (l->n_images == 1 && n > 0) {              // results ride in the same round trip as the statistics
+        HIPCHK(l, hipMemcpyAsync(l->h_u, l->st_u, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+        HIPCHK(l, hipMemcpyAsync(l->h_d, l->st_d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+    }
     rc = jsorb_sync(l);
     if (rc) return rc;
+    l->st_mirror_valid = l->n_images == 1;
     rc = jsorb_copy_stereo(l, 0, u_right, depth, stats);
     if (rc) return rc;
     if (stats) stats->n_right = jsorb_n_keypoints(r, 0);

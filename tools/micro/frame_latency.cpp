@@ -1,0 +1,54 @@
+// Per-frame latency of the reference-shaped synchronous API from C++ (no Python in the loop): what Frame::Frame's stereo
+// constructor costs per frame.  Usage: frame_latency H W L tile th fx bf left.raw right.raw [frames]
+// Build: g++ -O2 -std=c++17 -I include tools/micro/frame_latency.cpp -L jetson_slam_amd -ljsorb -lpthread -Wl,-rpath,$PWD/jetson_slam_amd
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "jsorb_compat.hpp"
+
+static std::vector<unsigned char> read_raw(const char *path, size_t n)
+{
+    std::vector<unsigned char> v(n);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(v.data(), 1, n, f) != n) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
+    fclose(f);
+    return v;
+}
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv)
+{
+    if (argc < 10) { fprintf(stderr, "usage\n"); return 2; }
+    const int H = atoi(argv[1]), W = atoi(argv[2]), L = atoi(argv[3]), tile = atoi(argv[4]), th = atoi(argv[5]);
+    const float fx = (float)atof(argv[6]), mbf = (float)atof(argv[7]);
+    const int frames = argc > 10 ? atoi(argv[10]) : 300;
+    auto imL = read_raw(argv[8], (size_t)H * W), imR = read_raw(argv[9], (size_t)H * W);
+    Jetson_SLAM::ORBExtractor exL(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
+    Jetson_SLAM::ORBExtractor exR(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
+    orb_cuda::SyncedMem<int> kpL, kpR;
+    orb_cuda::SyncedMem<unsigned char> dL, dR;
+    std::vector<float> mvuRight, mvDepth;
+    std::vector<jsorb_keypoint> keys, keysR;
+    std::vector<unsigned char> desc, descR;
+    double t_ext = 0, t_cpu = 0, t_st = 0, t_unp = 0;
+    for (int it = -20; it < frames; it++) {
+        const double t0 = now_us();
+        std::thread tl([&] { exL.extract(imL.data(), W, kpL, dL); });   // Frame.cpp:107-110
+        std::thread tr([&] { exR.extract(imR.data(), W, kpR, dR); });
+        tl.join(); tr.join();
+        const double t1 = now_us();
+        kpL.to_cpu(); kpR.to_cpu(); dL.to_cpu(); dR.to_cpu();           // Frame.cpp:119-122
+        const double t2 = now_us();
+        Jetson_SLAM::ComputeStereoMatches(exL, exR, mbf / fx, mbf, mvuRight, mvDepth);
+        const double t3 = now_us();
+        Jetson_SLAM::UnpackFrame(exL, keys, desc); Jetson_SLAM::UnpackFrame(exR, keysR, descR);      // alternative to the four to_cpu()
+        const double t4 = now_us();
+        if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; }
+    }
+    printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f\n",
+           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames);
+    return 0;
+}
