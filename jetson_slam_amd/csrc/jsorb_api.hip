@@ -174,6 +174,58 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
 }
 
 // FAST bounded-arc LUT (orb_gpu.cpp:367-436) for all 65536 indices, packed 1 bit per entry.
+// K3's horizontal reduction (orb_FAST_apply_NMS_G.cu:1318-1352) on one tile row of tw column winners: ceil-halving rounds,
+// slot j takes slot j+gs only if strictly greater, stale slots included.  Returns the winning column.
+static int tree_winner(const int *score, int tw, int log2_tw)
+{
+    int sc[128], col[128];
+    for (int j = 0; j < tw; j++) { sc[j] = score[j]; col[j] = j; }
+    int gs = (tw - 1) / 2 + 1;
+    for (int it = 0; it < log2_tw; it++) {
+        for (int j = 0; j < gs; j++)                       // reads of a round see the previous round's slots (j+gs >= gs is not written)
+            if (j + gs < tw && sc[j] < sc[j + gs]) { sc[j] = sc[j + gs]; col[j] = col[j + gs]; }
+        gs = (gs - 1) / 2 + 1;
+    }
+    return col[0];
+}
+
+// The tree above is a tournament in which the left slot wins ties, so among equal scores the winner is fixed by a priority order
+// of the columns.  The order is derived here from all pairwise duels and then CHECKED against the literal tree on random tie
+// sets; k_detect uses the arg-max form only if the check passes (otherwise it replays the tree literally).
+static bool build_tree_rank(int tw, int log2_tw, uint8_t *rank, uint8_t *inv)
+{
+    int sc[128];
+    std::vector<int> beaten(tw, 0);
+    for (int a = 0; a < tw; a++)
+        for (int b = a + 1; b < tw; b++) {
+            for (int j = 0; j < tw; j++) sc[j] = (j == a || j == b) ? 1 : 0;
+            const int w = tree_winner(sc, tw, log2_tw);
+            if (w != a && w != b) return false;
+            beaten[w == a ? b : a]++;
+        }
+    std::vector<int> seen(tw, 0);
+    for (int c = 0; c < tw; c++) {
+        if (beaten[c] < 0 || beaten[c] >= tw || seen[beaten[c]]) return false;      // not a total order
+        seen[beaten[c]] = 1;
+        rank[c] = (uint8_t)beaten[c];
+        inv[beaten[c]] = (uint8_t)c;
+    }
+    uint64_t rs = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+    for (int trial = 0; trial < 3000; trial++) {
+        // random scores with few distinct values (many ties), random active width like a tile at the right image border
+        const int levels = 1 + (int)(rnd() % 3), wa = trial % 5 == 0 ? 1 + (int)(rnd() % tw) : tw;
+        int best = -1, best_c = 0;
+        for (int j = 0; j < tw; j++) {
+            sc[j] = j < wa ? (int)(rnd() % (levels + 1)) : 0;
+            if (sc[j] > best || (sc[j] == best && rank[j] < rank[best_c])) { best = sc[j]; best_c = j; }
+        }
+        if (best == 0) best_c = 0;                          // nothing positive: slot 0 is never replaced
+        if (tree_winner(sc, tw, log2_tw) != best_c) return false;
+    }
+    return true;
+}
+
 void build_lut_bits(int nmin, int nmax, std::vector<uint32_t> &bits)
 {
     bits.assign(2048, 0u);
@@ -307,7 +359,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
             HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k], hipEventDisableTiming));
         }
     }
-    HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks) * sizeof(uint32_t)));      // arc LUT + workgroup tables
+    HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
     HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
@@ -351,7 +403,11 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
                 if (!((m0 | m8) & (m4 | m12))) g.lut_compass = 0;
             }
         // workgroup tables (jsorb_device.h, CTAB_*): level | tile row << 4 | tile column << 18
-        bits.resize(2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks);
+        bits.resize(2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS, 0u);
+        for (int i = 0; i < g.L; i++) {                    // column priorities of K3's horizontal tree (k_detect phase 3/4)
+            uint8_t *tr = reinterpret_cast<uint8_t *>(&bits[ctab_tree(g) + 64 * i]);
+            g.lv[i].tree_rank_ok = build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) ? 1 : 0;
+        }
         int btw, bth;
         blur_tile_dims(&btw, &bth);
         for (int i = 0; i < g.L; i++) {

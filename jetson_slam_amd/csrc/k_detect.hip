@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         uint4 *z = reinterpret_cast<uint4 *>(s_score);
         for (int i = tid; i < nsc; i += 256) z[i] = make_uint4(0, 0, 0, 0);
         if (tid < 128) s_colkey[tid] = 0;
+        if (lv.tree_rank_ok && tid < 64) reinterpret_cast<unsigned *>(s_tree)[tid] = lut_bits[ctab_tree(g) + 64 * lvl + tid];      // column priorities
     }
     __syncthreads();
 
@@ -283,9 +284,15 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     }
     __syncthreads();
 
-    // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + per-column max key, positives of the wave's own list ----
+    // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + arg-max key, positives of the wave's own list ----
+    // K3 picks, per tile, the maximum score; ties go first to the column the horizontal tree prefers, then inside the column to
+    // the smaller (ty, k).  When the host has verified that the tree is an arg-max with a fixed column priority (tree_rank_ok),
+    // one ds_max_u32 per positive on a per-TILE key (score << 18 | 127 - column priority << 11 | 2047 - row rank) yields the
+    // tile winner directly; otherwise the key is per column and phase 4 replays the tree.
     const int SW = L.score_w;
-    const int n_ty = lv.n_ty, recip_nty = (65536 + n_ty - 1) / n_ty;
+    const int n_ty = lv.n_ty, recip_nty = (65536 + n_ty - 1) / n_ty, recip_tw = (65536 + tw - 1) / tw;
+    const bool ranked = lv.tree_rank_ok != 0;
+    const unsigned char *s_rank = reinterpret_cast<const unsigned char *>(s_tree);      // rank[128], inv[128]
     for (int i = lane; i < n_pos; i += 64) {
         const int e = my_list[i], ry = e >> 8, rx = e & 255;
         if (ry < 1 || ry > th || rx < 1 || rx > ktw) continue;        // halo entries only serve as neighbours
@@ -297,9 +304,32 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         const int dy = ry - 1;
         const int kk = (dy * recip_nty) >> 16, ty = dy - kk * n_ty;      // dy / n_ty, exact for dy < 8192 (n_ty <= 8)
         const unsigned rank = (unsigned)(ty * 256 + kk);                 // lexicographic (ty, k); k < mini_tile <= 128
-        atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
+        if (ranked) {
+            const int tile = ((rx - 1) * recip_tw) >> 16, cit = rx - 1 - tile * tw;      // (rx-1) / tw, exact for rx-1 < 512
+            atomicMax(&s_colkey[tile], ((unsigned)s << 18) | ((127u - s_rank[cit]) << 11) | (2047u - rank));
+        } else {
+            atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
+        }
     }
     __syncthreads();
+
+    if (ranked) {
+        // ---- phase 4 (arg-max form): one thread per tile decodes the winner ----
+        if (tid < lv.k_tiles && xg0 + tid * tw < W) {
+            const unsigned key = s_colkey[tid];
+            const int sc = (int)(key >> 18);
+            int xx = xg0 + tid * tw, yy = y0;             // nothing positive: the tree keeps slot 0's initial value
+            if (sc > 0) {
+                const int rr = (int)(2047u - (key & 2047u));
+                xx += s_rank[128 + (127 - (int)((key >> 11) & 127u))];
+                yy = y0 + (rr >> 8) + (rr & 255) * n_ty;
+            }
+            const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tid;
+            tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] =
+                ((unsigned long long)(unsigned)sc << 32) | ((unsigned)(yy & 0xFFFF) << 16) | (unsigned)(xx & 0xFFFF);
+        }
+        return;
+    }
 
     // ---- phase 4: per-tile horizontal tree (literal replay of orb_FAST_apply_NMS_G.cu:1318-1352) ----
     // A slot of the reference's shared array always equals the current register value of its owner thread at a round
