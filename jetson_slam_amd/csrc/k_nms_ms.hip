@@ -14,8 +14,7 @@
 //    +-1 px, lower score dies, a tie kills the later one).
 // MI355X design: the reference keeps an L x H0 x W0 int32 scatter volume (23 MB per 752x480 image) plus two H0 x W0 planes and
 // clears one of them every frame; here ONE packed H0 x W0 accumulator per image (bits 0..23 sum, bits 24.. count) is updated
-// with atomics by the few thousand candidates and cleaned by them afterwards, so no plane is ever streamed.  One workgroup per
-// image; the three passes are separated by workgroup barriers.  CPU mode sorts (bin << 16 | index) keys with an in-LDS bitonic
+// with atomics by the few thousand candidates and cleaned by them afterwards, so no plane is ever streamed.  CPU mode sorts (bin << 16 | index) keys with an in-LDS bitonic
 // sort to recover the reference's insertion order, then one thread replays the pairwise loop of each bin.
 #include "jsorb_launch.h"
 
@@ -32,61 +31,47 @@ __device__ __forceinline__ int level_of_tile(const Geometry &g, int idx)
 
 #define MS_MARK (1ull << 63)
 
-__global__ __launch_bounds__(1024) void k_nms_ms_gpu(Geometry g, unsigned long long *tile_out, int *grid_all)
+// GPU-mode semantics as three grid-wide passes (one launch each: the kernel boundary is the "all adds before any read, all reads
+// before any zeroing" barrier).  A single workgroup per image with workgroup barriers between the passes was pure latency: 67 us
+// per 32 images at 752x480, 304 us at 1280x720 - longer than the FAST kernel.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_nms_ms_gpu(Geometry g, unsigned long long *tile_out, int *grid_all)
 {
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int idx = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (idx >= g.T) return;
     const int H0 = g.lv[0].H, W0 = g.lv[0].W, L = g.L;
     int *grid = grid_all + (size_t)b * H0 * W0;
     unsigned long long *t = tile_out + (size_t)b * g.T;
-    // pass A: scatter-add (score | 1<<24) into the level-0 accumulator
-    for (int idx = tid; idx < g.T; idx += 1024) {
-        const unsigned long long p = t[idx];
-        const int s = kp_score(p);
-        if (s) {
-            const float sc = g.lv[level_of_tile(g, idx)].scale;
-            const int h = (int)((float)kp_y(p) * sc), w = (int)((float)kp_x(p) * sc);
-            atomicAdd(&grid[(size_t)h * W0 + w], s | (1 << 24));
-        }
-    }
-    __threadfence();
-    __syncthreads();
-    // pass B: compare sum*zeros with the 3x3 neighbourhood (agent-scope loads: the cells were written by atomics at L2)
-    for (int idx = tid; idx < g.T; idx += 1024) {
-        const unsigned long long p = t[idx];
-        const int s = kp_score(p);
-        if (s) {
-            const float sc = g.lv[level_of_tile(g, idx)].scale;
-            const int h = (int)((float)kp_y(p) * sc), w = (int)((float)kp_x(p) * sc);
-            const int c = __hip_atomic_load(&grid[(size_t)h * W0 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int mine = (c & 0xFFFFFF) * (L - (c >> 24));
-            bool valid = true;
+    const unsigned long long p = t[idx];
+    const int s = kp_score(p);
+    if (!s) return;
+    const float sc = g.lv[level_of_tile(g, idx)].scale;
+    const int h = (int)((float)kp_y(p) * sc), w = (int)((float)kp_x(p) * sc);
+    if (PASS == 0) {
+        // pass A: scatter-add (score | 1<<24) into the level-0 accumulator
+        atomicAdd(&grid[(size_t)h * W0 + w], s | (1 << 24));
+    } else if (PASS == 1) {
+        // pass B: compare sum*zeros with the 3x3 neighbourhood
+        const int c = grid[(size_t)h * W0 + w];
+        const int mine = (c & 0xFFFFFF) * (L - (c >> 24));
+        bool valid = true;
 #pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
+        for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    const int hh = h + dy, ww = w + dx;
-                    int nb = 0;
-                    if (hh >= 0 && hh < H0 && ww >= 0 && ww < W0) {
-                        const int q = __hip_atomic_load(&grid[(size_t)hh * W0 + ww], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        nb = (q & 0xFFFFFF) * (L - (q >> 24));
-                    }
-                    valid = valid && (mine >= nb);
+            for (int dx = -1; dx <= 1; dx++) {
+                const int hh = h + dy, ww = w + dx;
+                int nb = 0;
+                if (hh >= 0 && hh < H0 && ww >= 0 && ww < W0) {
+                    const int q = grid[(size_t)hh * W0 + ww];
+                    nb = (q & 0xFFFFFF) * (L - (q >> 24));
                 }
-            if (!valid) t[idx] = p | MS_MARK;
-        }
-    }
-    __threadfence();
-    __syncthreads();
-    // pass C: clean the accumulator (it stays all-zero between frames) and apply the verdicts
-    for (int idx = tid; idx < g.T; idx += 1024) {
-        const unsigned long long p = t[idx];
-        const int s = kp_score(p);
-        if (s) {
-            const float sc = g.lv[level_of_tile(g, idx)].scale;
-            const int h = (int)((float)kp_y(p) * sc), w = (int)((float)kp_x(p) * sc);
-            __hip_atomic_store(&grid[(size_t)h * W0 + w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p & MS_MARK) t[idx] = p & ~(MS_MARK | (0xFFFull << 32));
-        }
+                valid = valid && (mine >= nb);
+            }
+        if (!valid) t[idx] = p | MS_MARK;
+    } else {
+        // pass C: clean the accumulator (it stays all-zero between frames) and apply the verdicts
+        grid[(size_t)h * W0 + w] = 0;
+        if (p & MS_MARK) t[idx] = p & ~(MS_MARK | (0xFFFull << 32));
     }
 }
 
@@ -169,7 +154,10 @@ __global__ __launch_bounds__(1024) void k_nms_ms_cpu(Geometry g, unsigned long l
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s)
 {
     if (mode_gpu) {
-        hipLaunchKernelGGL(k_nms_ms_gpu, dim3(n_images), dim3(1024), 0, s, g, tile_out, ms_grid);
+        const dim3 grid((g.T + 255) / 256, n_images);
+        hipLaunchKernelGGL(k_nms_ms_gpu<0>, grid, dim3(256), 0, s, g, tile_out, ms_grid);
+        hipLaunchKernelGGL(k_nms_ms_gpu<1>, grid, dim3(256), 0, s, g, tile_out, ms_grid);
+        hipLaunchKernelGGL(k_nms_ms_gpu<2>, grid, dim3(256), 0, s, g, tile_out, ms_grid);
     } else {
         int n_pad = 1024;
         while (n_pad < g.T) n_pad <<= 1;
