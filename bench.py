@@ -81,8 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
     ap.add_argument("--single-stream", action="store_true", help="all handles share one HIP stream (clean per-kernel times)")
-    ap.add_argument("--groups", type=int, default=4, help="the step's pairs are split over this many independent left/right handle pairs, "
-                    "one HIP stream per pair: kernels of different stages then overlap on the GPU (+6-8 %% over one pair of handles)")
+    ap.add_argument("--groups", type=int, default=0, help="the step's pairs are split over this many independent left/right handle pairs, "
+                    "one HIP stream per pair: kernels of different stages then overlap on the GPU (+6-8 %% over one pair of handles); "
+                    "0 = up to 4, keeping at least ~20 EuRoC-sized images per launch")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +113,13 @@ def main():
     left_d = torch.from_numpy(left_h).to(dev)
     right_d = torch.from_numpy(right_h).to(dev)
 
-    G = args.groups if args.groups >= 1 and P % max(1, args.groups) == 0 else 1
+    G = args.groups
+    if G <= 0:      # auto: launches stay large enough to fill the GPU (at least ~7 Mpx, i.e. ~20 images of 752x480, per launch)
+        G = max(1, min(4, int(P * H * W / 7.0e6)))
+        while P % G:
+            G -= 1
+    if P % G:
+        G = 1
     per = P // G                                  # pairs per handle pair and launch
     mk = lambda: orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, device_id=local_rank, max_batch=per)
     groups = [(mk(), mk()) for _ in range(G)]
