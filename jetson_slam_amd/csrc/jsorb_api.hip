@@ -407,6 +407,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         for (int i = 0; i < g.L; i++) {                    // column priorities of K3's horizontal tree (k_detect phase 3/4)
             uint8_t *tr = reinterpret_cast<uint8_t *>(&bits[ctab_tree(g) + 64 * i]);
             g.lv[i].tree_rank_ok = build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) ? 1 : 0;
+            if (getenv("JSORB_FORCE_TREE_REPLAY")) g.lv[i].tree_rank_ok = 0;      // test hook: keeps the literal replay covered
         }
         int btw, bth;
         blur_tile_dims(&btw, &bth);
