@@ -269,7 +269,8 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
 
 // 2.1 x median cut (orb_stereo_match.cu:563-578).  The median of the sorted (dist, idx) pairs is the (nv/2)-th smallest
 // distance; L1 distances are < 2^16 (121*510), so a two-pass 256-bin radix select in LDS finds it exactly.
-__global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restrict__ countsL, float *__restrict__ u_right,
+// generic form (any number of keypoints): three passes over the distances in memory, bin searches by thread 0
+__device__ __noinline__ void median_big(const Geometry &g, const int *__restrict__ countsL, float *__restrict__ u_right,
                                                 float *__restrict__ depth, const int *__restrict__ best_l1,
                                                 const unsigned *__restrict__ aux, int *__restrict__ stats)
 {
@@ -340,6 +341,107 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
     for (int i = tid; i < Nl; i += 256) {
         const int d = best_l1[tb + i];
         if (d >= 0 && !((float)d < thDist)) {
+            u_right[tb + i] = -1.0f;
+            depth[tb + i] = -1.0f;
+            removed++;
+        }
+    }
+    if (removed) atomicSub(&st[3], removed);
+}
+
+// exclusive prefix of one value per thread over the 256 threads of the workgroup (s_w: 4 ints of LDS scratch); also returns the total
+__device__ __forceinline__ int block256_exclusive_scan(int v, int *s_w, int &total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int incl = wave_inclusive_scan_i32(v);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    const int w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    total = w0 + w1 + w2 + w3;
+    const int base = wave == 0 ? 0 : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
+    __syncthreads();                                       // s_w may be reused by the next call
+    return base + incl - v;
+}
+
+// Same result as k_median_big for pairs with at most 256 * MED_R left keypoints: the L1 distances stay in registers over the three
+// passes and the two bin searches are workgroup prefix scans instead of 256-step loops of one thread (the kernel is one
+// workgroup per pair and pure latency: 18 us -> a few us per launch).
+#define MED_R 32
+__global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restrict__ countsL, float *__restrict__ u_right,
+                                                float *__restrict__ depth, const int *__restrict__ best_l1,
+                                                const unsigned *__restrict__ aux, int *__restrict__ stats)
+{
+    __shared__ int hist[256];
+    __shared__ int sel[4];
+    __shared__ int s_w[4];
+    __shared__ int s_cand, s_corr;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
+    const size_t tb = (size_t)b * g.T;
+    int *st = stats + b * 8;
+    if (Nl > 256 * MED_R) {                                // wave-uniform: too many keypoints for the register-resident form
+        median_big(g, countsL, u_right, depth, best_l1, aux, stats);
+        return;
+    }
+    hist[tid] = 0;
+    if (tid == 0) { s_cand = 0; s_corr = 0; }
+    int d[MED_R];
+    int cand = 0, corr = 0;
+#pragma unroll
+    for (int r = 0; r < MED_R; r++) {
+        const int i = tid + 256 * r;
+        d[r] = -1;
+        if (i < Nl) {
+            d[r] = best_l1[tb + i];
+            const unsigned a = aux[tb + i];
+            cand += (int)(a & 0x7FFFFFFFu);
+            corr += (int)(a >> 31);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MED_R; r++)
+        if (d[r] >= 0) atomicAdd(&hist[(d[r] >> 8) & 255], 1);
+    cand = wave_sum_i32(cand);
+    corr = wave_sum_i32(corr);
+    if ((tid & 63) == 0) { atomicAdd(&s_cand, cand); atomicAdd(&s_corr, corr); }
+    __syncthreads();
+    if (tid == 0) { st[0] = s_cand; st[1] = s_corr; }
+    // the (nv/2)-th smallest distance: bin of the high byte, then of the low byte inside that bin
+    int nv;
+    {
+        const int h = hist[tid];
+        const int excl = block256_exclusive_scan(h, s_w, nv);
+        const int kth = nv / 2;
+        if (h > 0 && excl <= kth && kth < excl + h) { sel[0] = tid; sel[1] = kth - excl; }      // exactly one bin (nv > 0)
+    }
+    if (tid == 0) st[2] = nv;
+    if (nv == 0) {              // Appendix C-6: nothing matched -> no cut
+        if (tid == 0) st[3] = 0;
+        return;
+    }
+    hist[tid] = 0;
+    __syncthreads();
+    const int bin = sel[0], kin = sel[1];
+#pragma unroll
+    for (int r = 0; r < MED_R; r++)
+        if (d[r] >= 0 && ((d[r] >> 8) & 255) == bin) atomicAdd(&hist[d[r] & 255], 1);
+    __syncthreads();
+    {
+        const int h = hist[tid];
+        int tot;
+        const int excl = block256_exclusive_scan(h, s_w, tot);
+        if (h > 0 && excl <= kin && kin < excl + h) sel[3] = (bin << 8) | tid;
+        if (tid == 0) st[3] = nv;
+    }
+    __syncthreads();
+    const float median = (float)sel[3];
+    const float thDist = 1.5f * 1.4f * median;
+    int removed = 0;
+#pragma unroll
+    for (int r = 0; r < MED_R; r++) {
+        const int i = tid + 256 * r;
+        if (d[r] >= 0 && !((float)d[r] < thDist)) {
             u_right[tb + i] = -1.0f;
             depth[tb + i] = -1.0f;
             removed++;
