@@ -95,12 +95,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    if os.environ.get("JSORB_BENCH_SINGLE_DEVICE"):       # test hook: every rank on cuda:0 (exercises the N > 1 code path on a 1-GPU box)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("JSORB_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for the test hook above
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
     H, W, L, tile, th, fx, bf = cfg
@@ -140,8 +146,10 @@ def main():
             group_streams.append(st)
             a.set_stream(st.cuda_stream)
             b.set_stream(st.cuda_stream)
-    counts_d = torch.zeros(P * 3, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros_like(counts_d) for _ in range(world)] if world > 1 else None
+    # payload of the collective, double-buffered: the gather kernels of step k+1 must not overwrite what the all_gather of step k reads
+    counts_bufs = [torch.zeros(P * 3, dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros_like(counts_bufs[0]) for _ in range(world)] if world > 1 else None
+    step_no = [0]
     mb = bf / fx
 
     def step():
@@ -151,6 +159,8 @@ def main():
         for a, b in groups:
             orb.stereo_match_batch_async(a, b, mb, bf)
         if world > 1:   # the one collective of the path: per-pair (N_left, N_right, N_matched), <1 KB per rank
+            counts_d = counts_bufs[step_no[0] & 1]
+            step_no[0] += 1
             for gi, (a, b) in enumerate(groups):
                 orb.gather_counts_async(a, b, counts_d[gi * per * 3:].data_ptr())
                 a.stream_wait_done(torch_stream_ptr)    # RCCL is issued from torch's stream: order it after the left streams
