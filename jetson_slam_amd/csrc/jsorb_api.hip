@@ -340,6 +340,10 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     e->stream = e->own_stream;
     HIPCHK(e, hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->readers_done, hipEventDisableTiming));
+    for (int i = 0; i < g.L; i++) {                        // needed by the LDS layout: the arg-max form needs 256 B where the literal tree needs 1 KB
+        uint8_t tr[256];
+        g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !getenv("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
+    }
     fill_detect_layout(g);
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
@@ -406,8 +410,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         bits.resize(2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS, 0u);
         for (int i = 0; i < g.L; i++) {                    // column priorities of K3's horizontal tree (k_detect phase 3/4)
             uint8_t *tr = reinterpret_cast<uint8_t *>(&bits[ctab_tree(g) + 64 * i]);
-            g.lv[i].tree_rank_ok = build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) ? 1 : 0;
-            if (getenv("JSORB_FORCE_TREE_REPLAY")) g.lv[i].tree_rank_ok = 0;      // test hook: keeps the literal replay covered
+            (void)build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128);      // tree_rank_ok was decided before the LDS layout (JSORB_FORCE_TREE_REPLAY: test hook)
         }
         int btw, bth;
         blur_tile_dims(&btw, &bth);

@@ -39,7 +39,7 @@ struct DetectLds {
     size_t off_score, off_list, off_colkey, off_tree, total;
 };
 
-__host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_tiles)
+__host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_tiles, int ranked)
 {
     DetectLds d;
     const int ktw = k_tiles * tw;
@@ -59,7 +59,7 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     d.off_colkey = o;
     o += 128 * 4;
     d.off_tree = o;
-    o += 128 * 8;
+    o += ranked ? 256 : 128 * 8;                   // column priorities (rank[128], inv[128]) or the literal tree's 128 slots
     d.total = o;
     return d;
 }
@@ -68,7 +68,7 @@ void fill_detect_layout(Geometry &g)
 {
     for (int i = 0; i < g.L; i++) {
         LevelDesc &lv = g.lv[i];
-        const DetectLds d = detect_lds_layout(lv.th, lv.tw, lv.k_tiles);
+        const DetectLds d = detect_lds_layout(lv.th, lv.tw, lv.k_tiles, lv.tree_rank_ok);
         lv.det_score_w = d.score_w; lv.det_score_rows = d.score_rows; lv.det_img_rows = d.img_rows; lv.det_list_cap = d.list_cap;
         lv.det_off_score = (int)d.off_score; lv.det_off_list = (int)d.off_list; lv.det_off_colkey = (int)d.off_colkey; lv.det_off_tree = (int)d.off_tree;
     }
@@ -78,7 +78,7 @@ size_t detect_lds_bytes(const Geometry &g)
 {
     size_t m = 0;
     for (int i = 0; i < g.L; i++) {
-        DetectLds d = detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles);
+        DetectLds d = detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok);
         if (d.total > m) m = d.total;
     }
     return m;
