@@ -164,7 +164,10 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         bblk += lv.blur_bx * lv.blur_by;
         lv.pyr_bx = (lv.W + PYR_TW - 1) / PYR_TW; // k_pyramid: PYR_TW x PYR_TH output tile per workgroup
         lv.pyr_blk0 = pblk;
-        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + PYR_TH - 1) / PYR_TH);
+        // 16 output rows per workgroup while their level-0 window stays small; the high levels fall back to 8 so that the
+        // launch-wide LDS size (the maximum over the levels) keeps 8 workgroups per CU (k_pyramid is occupancy sensitive)
+        lv.pyr_th = pyramid_window_bytes(lv.pyr_s, PYR_TH) <= 12 * 1024 ? PYR_TH : 8;
+        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + lv.pyr_th - 1) / lv.pyr_th);
     }
     g.T = tiles;
     if (tiles >= (1 << 20)) { err = "too many tiles"; return JSORB_ERR_INVALID; }
@@ -423,7 +426,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
                 for (int bx = 0; bx < lv.blur_bx; bx++)
                     bits[ctab_blur(g) + lv.blur_blk0 + by * lv.blur_bx + bx] = (uint32_t)i | ((uint32_t)by << 4) | ((uint32_t)bx << 18);
             if (i >= 1)
-                for (int by = 0; by < (lv.H + PYR_TH - 1) / PYR_TH; by++)
+                for (int by = 0; by < (lv.H + lv.pyr_th - 1) / lv.pyr_th; by++)
                     for (int bx = 0; bx < lv.pyr_bx; bx++)
                         bits[ctab_pyramid(g) + lv.pyr_blk0 + by * lv.pyr_bx + bx] = (uint32_t)i | ((uint32_t)by << 4) | ((uint32_t)bx << 18);
         }

@@ -20,6 +20,7 @@ struct StereoArgs {
 size_t detect_lds_bytes(const Geometry &g);
 
 size_t pyramid_lds_bytes(const Geometry &g);
+size_t pyramid_window_bytes(float s, int rows_out);      // LDS bytes of the level-0 window of one k_pyramid tile
 void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, const uint32_t *ctab, int n_images, size_t lds_bytes, hipStream_t s);
 void fill_detect_layout(Geometry &g);      // per-level LDS layout of k_detect (host side, once per handle)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
