@@ -128,12 +128,9 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             }
         }
     }
-#pragma unroll
-    for (int off = SGL / 2; off > 0; off >>= 1) {     // reduce inside the keypoint's lane group
-        const unsigned o = (unsigned)__shfl_xor((int)best_key, off, 64);
-        best_key = o < best_key ? o : best_key;
-        n_cand += __shfl_xor(n_cand, off, 64);
-    }
+    static_assert(SGL == 16, "the lane group of a keypoint is one DPP row");
+    best_key = row16_min_u32(best_key);               // reduce inside the keypoint's lane group
+    n_cand = row16_sum_i32(n_cand);
 
     // ---- sub-pixel refinement of the best match (all lanes of the group hold the same values) ----
     float out_u = -1.0f, out_d = -1.0f;
