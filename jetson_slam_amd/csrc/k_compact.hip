@@ -55,10 +55,92 @@ __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned lon
     if (tid == 0) counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = base;
 }
 
+// Flat form for T <= 65536 candidates: one pass stores the wave ballots of all 1024-entry chunks, one workgroup prefix scan turns
+// them into start positions, a second pass writes; positions of arbitrary candidates (tile-row starts, level boundaries) are then
+// read off the same tables.  Three barriers instead of two per level and chunk - the kernel is one workgroup per image and pure
+// latency.
+#define CMP_MAX_CHUNKS 64
+__device__ __forceinline__ int compact_pos_of(int j, int T, int total, const unsigned long long *s_bal, const int *s_base)
+{
+    if (j >= T) return total;
+    const int cell = j >> 6;                                  // chunk * 16 + wave
+    return s_base[cell] + __popcll(s_bal[cell] & ((1ull << (j & 63)) - 1ull));
+}
+
+__global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigned long long *__restrict__ tile_out,
+                                                       unsigned long long *__restrict__ kp, int *__restrict__ counts,
+                                                       int *__restrict__ row_tab)
+{
+    __shared__ unsigned long long s_bal[CMP_MAX_CHUNKS * 16];
+    __shared__ int s_base[CMP_MAX_CHUNKS * 16];
+    __shared__ int s_wtot[16];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, T = g.T;
+    const unsigned long long *tin = tile_out + (size_t)b * T;
+    unsigned long long *kout = kp + (size_t)b * T;
+    int *rt = row_tab + (size_t)b * g.row_tab_len;
+    const int n_chunks = (T + 1023) >> 10, n_cells = n_chunks * 16;
+    for (int c = 0; c < n_chunks; c++) {
+        const int j = c * 1024 + tid;
+        const unsigned long long p = j < T ? tin[j] : 0ull;
+        const unsigned long long bal = __ballot(kp_score(p) > 0);
+        if (lane == 0) s_bal[c * 16 + wave] = bal;
+    }
+    __syncthreads();
+    {   // exclusive prefix over the n_cells <= 1024 cells (one per thread)
+        const int v = tid < n_cells ? __popcll(s_bal[tid]) : 0;
+        const int incl = wave_inclusive_scan_i32(v);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int t = s_wtot[w];
+            if (w < wave) base += t;
+            tot += t;
+        }
+        if (tid < n_cells) s_base[tid] = base + incl - v;
+        if (tid == 0) s_total = tot;
+    }
+    __syncthreads();
+    const int total = s_total;
+    for (int c = 0; c < n_chunks; c++) {
+        const int j = c * 1024 + tid;
+        if (j >= T) break;
+        const unsigned long long p = tin[j];
+        if (kp_score(p) > 0) {
+            int lvl = 0;
+#pragma unroll 1
+            for (int i = 1; i < g.L; i++)
+                if (j >= g.lv[i].tile_off) lvl = i;
+            kout[compact_pos_of(j, T, total, s_bal, s_base)] = p | ((unsigned long long)lvl << 44);
+        }
+    }
+    // first keypoint of every tile row (+ the end of each level), per-level counts
+    for (int t = tid; t < g.row_tab_len; t += 1024) {
+        int lvl = 0;
+#pragma unroll 1
+        for (int i = 1; i < g.L; i++)
+            if (t >= g.lv[i].row_tab_off) lvl = i;
+        const LevelDesc &lv = g.lv[lvl];
+        const int k = t - lv.row_tab_off;                     // 0 .. nth
+        rt[t] = compact_pos_of(lv.tile_off + k * lv.ntw, T, total, s_bal, s_base);
+    }
+    if (tid < g.L) {
+        const int j0 = g.lv[tid].tile_off, j1 = tid + 1 < g.L ? g.lv[tid + 1].tile_off : T;
+        counts[b * (JSORB_MAX_LEVELS + 1) + tid] = compact_pos_of(j1, T, total, s_bal, s_base) - compact_pos_of(j0, T, total, s_bal, s_base);
+    }
+    if (tid == 0) counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = total;
+}
+
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_compact, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab);
+    if (g.T <= CMP_MAX_CHUNKS * 1024)
+        hipLaunchKernelGGL(k_compact_flat, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab);
+    else
+        hipLaunchKernelGGL(k_compact, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab);
 }
 
 } // namespace jsorb
