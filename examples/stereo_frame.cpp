@@ -36,9 +36,35 @@ int main(int argc, char **argv)
         std::thread tr([&] { exR.extract(imR.data(), W, kpR, dR); });
         tl.join(); tr.join();
         kpL.to_cpu(); kpR.to_cpu(); dL.to_cpu(); dR.to_cpu();           // Frame.cpp:119-122
-        std::vector<float> mvuRight, mvDepth;
-        Jetson_SLAM::ComputeStereoMatches(exL, exR, mbf / fx, mbf, mvuRight, mvDepth);
         const int nl = kpL.count_ / 6, nr = kpR.count_ / 6;
+        // Frame::ComputeStereoMatches exactly as the reference writes it (Frame.cpp:780-803): members of orb_cuda::ORB_GPU
+        struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };       // stands in for cv::KeyPoint
+        std::vector<KeyPoint> mvKeysRef(nl), mvKeysRightRef(nr);
+        std::vector<float> mvuRight, mvDepth;
+        const float mb = mbf / fx;
+        {
+            orb_cuda::ORB_GPU &orb_exl = *exL.orb_gpu_;
+            orb_cuda::ORB_GPU &orb_exr = *exR.orb_gpu_;
+            orb_exl.ORB_compute_stereo_match(100, 50, mb, mbf, orb_exl.height_, orb_exl.width_, mvKeysRef, mvKeysRightRef, mvuRight, mvDepth,
+                                             dL.gpu_data(), dR.gpu_data(), orb_exl.image_, orb_exr.image_);
+        }
+        {   // the free-function form must give the same bits
+            std::vector<float> u2, d2;
+            Jetson_SLAM::ComputeStereoMatches(exL, exR, mb, mbf, u2, d2);
+            if (u2.size() != mvuRight.size() || memcmp(u2.data(), mvuRight.data(), 4 * u2.size()) || memcmp(d2.data(), mvDepth.data(), 4 * d2.size())) {
+                fprintf(stderr, "the two ComputeStereoMatches forms differ\n");
+                return 3;
+            }
+        }
+        {   // SyncedMem keeps its own device copy of the results (the reference's extract() writes into the caller's SyncedMem):
+            // pull it back with a real device-to-host copy and compare with the host side delivered by extract()
+            std::vector<int> host_side(kpL.cpu_data(), kpL.cpu_data() + kpL.count_);
+            (void)kpL.gpu_data();                 // invalidates the "host copy is fresh" shortcut
+            memset(kpL.cpu_data(), 0xEE, sizeof(int) * kpL.count_);
+            kpL.to_cpu_async();
+            kpL.sync_stream();
+            if (memcmp(host_side.data(), kpL.cpu_data(), sizeof(int) * kpL.count_)) { fprintf(stderr, "SyncedMem device copy differs from host copy\n"); return 3; }
+        }
         FILE *f = fopen(argv[10], "wb");
         fwrite(&nl, 4, 1, f); fwrite(&nr, 4, 1, f);
         fwrite(kpL.cpu_data(), 4, 6 * (size_t)nl, f); fwrite(dL.cpu_data(), 1, 32 * (size_t)nl, f);

@@ -102,6 +102,9 @@ float jsorb_inv_scale(const jsorb_extractor *e, int level);
 /* Device pointer to the un-blurred (blurred=0) or 7x7-blurred (blurred=1) pyramid level of an image (ORB_GPU::image_/image_gaussian_). */
 const uint8_t *jsorb_level_image_device(const jsorb_extractor *e, int image, int level, int blurred);
 int jsorb_copy_level_image(const jsorb_extractor *e, int image, int level, int blurred, uint8_t *host_dst /* H*W, pitch W */);
+/* The per-level feature mask (ORB_GPU::masks_[level], orb_gpu.cpp:64-91: cv::resize(INTER_NN) of the level-0 mask, then
+ * threshold(10)): H*W bytes 0 / 255, pitch W; all 255 when the handle has no mask. */
+int jsorb_copy_level_mask(const jsorb_extractor *e, int level, uint8_t *host_dst);
 /* Per-tile candidates before compaction (x,y,score), T entries each: debugging / stage-level parity. */
 int jsorb_copy_tile_candidates(const jsorb_extractor *e, int image, int32_t *x, int32_t *y, int32_t *score);
 /* Per-keypoint orientation in radians in output order (N floats). */
@@ -151,6 +154,31 @@ int jsorb_unpack_frame(jsorb_extractor *e, int image, jsorb_keypoint *keypoints,
  * rectified stereo).  Host destinations; cols*rows <= 16384. */
 int jsorb_assign_features_to_grid(jsorb_extractor *e, int image, float min_x, float min_y, float grid_element_width_inv,
                                   float grid_element_height_inv, int cols, int rows, int32_t *cell_start, int32_t *cell_items);
+
+/* ---- memory: what orb_cuda::SyncedMem<T> needs (include/cuda/synced_mem_holder.hpp:10-65, src/cuda/synced_mem_holder.cpp:8-199) ----
+ * The reference's untouched host code (ORBmatcher.cpp:1673-1877, Tracking.cpp:1427-1600, orb_stereo_match.cu statics) allocates
+ * pinned-host + device buffer pairs and moves data with cudaMemcpy(Async) on a private stream; these calls are the HIP side of
+ * that, so that include/jsorb_compat.hpp can offer the full SyncedMem surface without the consumer including a HIP header.
+ * They act on the calling thread's current device (jsorb_mem_set_device), like the CUDA runtime calls they replace.
+ * `stream` is a hipStream_t as void*; NULL = the null stream (blocking calls) / synchronous copy. */
+int jsorb_mem_set_device(int device_id);
+int jsorb_mem_alloc_host(size_t bytes, void **host_pinned);                  /* cudaMallocHost  (synced_mem_holder.cpp:63) */
+int jsorb_mem_alloc_device(size_t bytes, void **device);                     /* cudaMalloc      (:67) */
+int jsorb_mem_alloc_device_pitched(size_t width_bytes, size_t height, void **device, size_t *pitch);   /* cudaMallocPitch (:50) */
+int jsorb_mem_free_host(void *host_pinned);                                  /* cudaFreeHost */
+int jsorb_mem_free_device(void *device);                                     /* cudaFree */
+int jsorb_mem_stream_create(void **stream);                                  /* cudaStreamCreate (:19) */
+int jsorb_mem_stream_destroy(void *stream);
+int jsorb_mem_stream_sync(void *stream);                                     /* cudaStreamSynchronize (:190) */
+int jsorb_mem_h2d(void *device_dst, const void *host_src, size_t bytes);     /* cudaMemcpy HostToDevice (:96) */
+int jsorb_mem_d2h(void *host_dst, const void *device_src, size_t bytes);     /* cudaMemcpy DeviceToHost (:90) */
+int jsorb_mem_d2d(void *device_dst, const void *device_src, size_t bytes);
+int jsorb_mem_h2d_async(void *device_dst, const void *host_src, size_t bytes, void *stream);   /* cudaMemcpyAsync (:128) */
+int jsorb_mem_d2h_async(void *host_dst, const void *device_src, size_t bytes, void *stream);   /* cudaMemcpyAsync (:122) */
+int jsorb_mem_d2d_async(void *device_dst, const void *device_src, size_t bytes, void *stream);
+int jsorb_mem_set_zero(void *device, size_t bytes);                          /* cudaMemset (:109) */
+int jsorb_mem_set_zero_async(void *device, size_t bytes, void *stream);      /* cudaMemsetAsync (:115) */
+const char *jsorb_mem_last_error(void);                                      /* text of the last failed jsorb_mem_* call of this thread */
 
 /* ---- plumbing ---- */
 /* Use an external HIP stream (hipStream_t as void*) instead of the handle's own, e.g. torch's current stream. NULL restores. */

@@ -1,15 +1,24 @@
-// jsorb_compat.hpp - header-only C++ shim that recreates the reference's front-end interface on top of the C ABI
-// (include/jsorb.h), so that Frame / Tracking code keeps compiling against the same names:
+// jsorb_compat.hpp - header-only C++ shim that recreates the reference's GPU-side interface on top of the C ABI (include/jsorb.h),
+// so that Frame / Tracking / ORBmatcher keep compiling against the same names.  It stands in for these reference headers:
 //
-//   orb_cuda::SyncedMem<T>          include/cuda/synced_mem_holder.hpp:10-65   (count_, cpu_data(), gpu_data(), to_cpu(), resize())
-//   Jetson_SLAM::ORBExtractor       include/ORBextractor.h:21-93               (ctor argument order, extract(), get_* tables)
-//   Jetson_SLAM::ComputeStereoMatches  = body of Frame::ComputeStereoMatches   src/Frame.cpp:780-803
+//   include/cuda/synced_mem_holder.hpp:10-65   orb_cuda::SyncedMem<T>     every member: count_, capacity_, cpu_data_, gpu_data_, pitch_,
+//                                                                         cu_stream_, resize, resize_pitched, cpu_data, gpu_data,
+//                                                                         to_cpu/to_gpu (+count, +async, +stream), sync_stream, set_zero_*
+//   include/cuda/orb_gpu.hpp:22-250            orb_cuda::ORB_GPU          ctor argument order, extract(), ORB_compute_stereo_match(),
+//                                                                         height_, width_, scale_, inv_scale_, image_ (what Frame.cpp:780-803 touches)
+//   include/cuda/orb_matcher.hpp:12-24         orb_cuda::ORB_Search_by_projection_project_on_frame, ORB_compute_distances
+//   include/cuda/tracking_gpu.hpp:14-31        tracking_cuda::compute_isInFrustum_GPU
+//   include/ORBextractor.h:21-93               Jetson_SLAM::ORBExtractor  ctor argument order, extract(), get_* tables, orb_gpu_
 //
-// No HIP / OpenCV header is needed by the consumer: device->host copies go through the ABI.  Define JSORB_WITH_OPENCV
-// before including to get the cv::Mat overload of extract().
+// plus three helpers that are the bodies of Frame.cpp:119-196 (UnpackFrame), :463-479 (AssignFeaturesToGrid) and a free-function form of
+// Frame::ComputeStereoMatches.  No HIP / CUDA / OpenCV header is needed by the consumer: all device work goes through the ABI.
+// Define JSORB_WITH_OPENCV before including to get the cv::Mat / cv::KeyPoint overloads (the exact reference signatures) and mask
+// loading through cv::imread; without it masks are read from binary PGM / PPM files.
 #ifndef JSORB_COMPAT_HPP
 #define JSORB_COMPAT_HPP
 
+#include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -18,41 +27,327 @@
 
 #ifdef JSORB_WITH_OPENCV
 #include <opencv2/core.hpp>
+#include <opencv2/imgcodecs.hpp>
+#include <opencv2/imgproc.hpp>
+#endif
+
+// The reference's host code names these CUDA types (SyncedMem::cu_stream_, to_cpu_async(cudaStream_t&)); they are opaque here.
+#ifndef JSORB_NO_CUDA_TYPEDEFS
+typedef void *cudaStream_t;
+typedef int cudaError_t;
 #endif
 
 namespace orb_cuda {
 
-// Result holder with the reference's SyncedMem surface.  The device side is a VIEW of the extractor's result buffers
-// (valid until the next extract on that extractor, exactly like the reference, whose extract() resizes and refills the
-// caller's SyncedMem); the host side is owned.
+// orb_cuda::SyncedMem<T> (synced_mem_holder.hpp:10-65, synced_mem_holder.cpp:8-199): a pinned host buffer + a device buffer of
+// capacity_ elements and a private stream.  Same semantics: resize() grows only and never clears; the to_* calls copy count_
+// (or the given count) elements; the *_async forms run on cu_stream_ (or the given stream) and sync_stream() waits for cu_stream_.
+// Errors are recorded in cu_error_ and otherwise ignored, as in the reference (every method there is void).
 template <typename Dtype>
 class SyncedMem {
 public:
-    int count_ = 0;
-    const Dtype *gpu_data_ = nullptr;
-    std::vector<Dtype> cpu_;
+    SyncedMem() : count_(0), capacity_(0), cpu_data_(nullptr), gpu_data_(nullptr), pitch_(0), cu_stream_(nullptr), cu_error_(0)
+    {
+        cu_error_ = jsorb_mem_stream_create(&cu_stream_);
+    }
+    ~SyncedMem()
+    {
+        if (cu_stream_) { jsorb_mem_stream_sync(cu_stream_); jsorb_mem_stream_destroy(cu_stream_); }
+        cu_stream_ = nullptr;
+        if (cpu_data_) jsorb_mem_free_host(cpu_data_);
+        if (gpu_data_) jsorb_mem_free_device(gpu_data_);
+    }
+    // the reference's implicit copy would double-free; moves are what std::vector<SyncedMem<T>>::resize needs
+    SyncedMem(const SyncedMem &) = delete;
+    SyncedMem &operator=(const SyncedMem &) = delete;
+    SyncedMem(SyncedMem &&o) noexcept
+        : count_(o.count_), capacity_(o.capacity_), cpu_data_(o.cpu_data_), gpu_data_(o.gpu_data_), pitch_(o.pitch_), cu_stream_(o.cu_stream_),
+          cu_error_(o.cu_error_), host_fresh_(o.host_fresh_)
+    {
+        o.count_ = o.capacity_ = 0; o.cpu_data_ = nullptr; o.gpu_data_ = nullptr; o.cu_stream_ = nullptr;
+    }
 
-    void resize(int count) { count_ = count; if ((int)cpu_.size() < count) cpu_.resize(count); }
-    Dtype *cpu_data() { return cpu_.data(); }
-    const Dtype *gpu_data() const { return gpu_data_; }
-    // filled by ORBExtractor::extract
-    const jsorb_extractor *owner_ = nullptr;
-    int image_ = 0;
-    void to_cpu();
+    void resize(int count)
+    {
+        count_ = count;
+        host_fresh_ = false;
+        if (capacity_ < count_) {
+            capacity_ = count_;
+            if (cpu_data_) jsorb_mem_free_host(cpu_data_);
+            cpu_data_ = nullptr;
+            note(jsorb_mem_alloc_host((size_t)capacity_ * sizeof(Dtype), (void **)&cpu_data_));
+            if (gpu_data_) jsorb_mem_free_device(gpu_data_);
+            gpu_data_ = nullptr;
+            note(jsorb_mem_alloc_device((size_t)capacity_ * sizeof(Dtype), (void **)&gpu_data_));
+        }
+    }
+    void resize_pitched(size_t width, size_t height)
+    {
+        count_ = (int)(width * height);
+        host_fresh_ = false;
+        if (cpu_data_) jsorb_mem_free_host(cpu_data_);
+        cpu_data_ = nullptr;
+        note(jsorb_mem_alloc_host((size_t)count_ * sizeof(Dtype), (void **)&cpu_data_));
+        if (gpu_data_) jsorb_mem_free_device(gpu_data_);
+        gpu_data_ = nullptr;
+        note(jsorb_mem_alloc_device_pitched(width * sizeof(Dtype), height, (void **)&gpu_data_, &pitch_));
+    }
+
+    Dtype *cpu_data() { return cpu_data_; }
+    Dtype *gpu_data() { host_fresh_ = false; return gpu_data_; }      // the caller may write through it: the host copy is no longer known to be current
+
+    void to_cpu(void) { to_cpu(count_); }
+    void to_gpu(void) { to_gpu(count_); }
+    void to_cpu(int count)
+    {
+        if (host_fresh_ && count <= count_) return;      // ORBExtractor::extract already delivered the host copy with the device copy
+        note(jsorb_mem_d2h(cpu_data_, gpu_data_, (size_t)count * sizeof(Dtype)));
+    }
+    void to_gpu(int count) { host_fresh_ = false; note(jsorb_mem_h2d(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype))); }
+    void to_cpu_async(void) { to_cpu_async(cu_stream_, count_); }
+    void to_gpu_async(void) { to_gpu_async(cu_stream_, count_); }
+    void to_cpu_async(cudaStream_t &cu_stream) { to_cpu_async(cu_stream, count_); }
+    void to_gpu_async(cudaStream_t &cu_stream) { to_gpu_async(cu_stream, count_); }
+    void to_cpu_async(int count) { to_cpu_async(cu_stream_, count); }
+    void to_gpu_async(int count) { to_gpu_async(cu_stream_, count); }
+    void to_cpu_async(cudaStream_t &cu_stream, int count)
+    {
+        if (host_fresh_ && count <= count_) return;
+        note(jsorb_mem_d2h_async(cpu_data_, gpu_data_, (size_t)count * sizeof(Dtype), cu_stream));
+    }
+    void to_gpu_async(cudaStream_t &cu_stream, int count)
+    {
+        host_fresh_ = false;
+        note(jsorb_mem_h2d_async(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype), cu_stream));
+    }
+    void sync_stream(void) { note(jsorb_mem_stream_sync(cu_stream_)); }
+    void set_zero_gpu(void) { host_fresh_ = false; note(jsorb_mem_set_zero(gpu_data_, (size_t)count_ * sizeof(Dtype))); }
+    void set_zero_gpu_async(void) { host_fresh_ = false; note(jsorb_mem_set_zero_async(gpu_data_, (size_t)count_ * sizeof(Dtype), cu_stream_)); }
+    void set_zero_cpu(void) { host_fresh_ = false; if (cpu_data_) memset(cpu_data_, 0, (size_t)count_ * sizeof(Dtype)); }
+
+    // public in the reference ("//private:" is commented out there)
+    int count_;
+    int capacity_;
+    Dtype *cpu_data_;
+    Dtype *gpu_data_;
+    size_t pitch_;
+    cudaStream_t cu_stream_;
+    cudaError_t cu_error_;
+
+    // set by ORB_GPU::extract when it fills both sides in one go (the four blocking to_cpu() of Frame.cpp:119-122 then cost nothing)
+    bool host_fresh_ = false;
+
+private:
+    void note(int rc) { if (rc != JSORB_OK) cu_error_ = rc; }
 };
 
-template <>
-inline void SyncedMem<int>::to_cpu()
+// orb_cuda::ORB_Search_by_projection_project_on_frame (orb_matcher.hpp:12-18, orb_matcher.cu:62-89): synchronous, device pointers
+inline void ORB_Search_by_projection_project_on_frame(int n_points, float *Px_gpu, float *Py_gpu, float *Pz_gpu, float *Rcw_gpu, float *tcw_gpu,
+                                                      float &fx, float &fy, float &cx, float &cy, float &minX, float &maxX, float &minY, float &maxY,
+                                                      float *u_gpu, float *v_gpu, float *invz_gpu, unsigned char *is_valid_gpu)
 {
-    if (owner_ && count_ > 0 && jsorb_copy_keypoints(owner_, image_, cpu_.data()) != JSORB_OK) throw std::runtime_error("jsorb_copy_keypoints failed");
+    if (jsorb_project_points(nullptr, n_points, Px_gpu, Py_gpu, Pz_gpu, Rcw_gpu, tcw_gpu, fx, fy, cx, cy, minX, maxX, minY, maxY, u_gpu, v_gpu, invz_gpu,
+                             is_valid_gpu) != JSORB_OK)
+        throw std::runtime_error("jsorb_project_points failed");
 }
-template <>
-inline void SyncedMem<unsigned char>::to_cpu()
+// orb_cuda::ORB_compute_distances (orb_matcher.hpp:20-24, orb_matcher.cu:122-144)
+inline void ORB_compute_distances(int n_points, int *idx_left, int *idx_right, unsigned char *descriptor_left, unsigned char *descriptor_right, int *distance)
 {
-    if (owner_ && count_ > 0 && jsorb_copy_descriptors(owner_, image_, cpu_.data()) != JSORB_OK) throw std::runtime_error("jsorb_copy_descriptors failed");
+    if (jsorb_hamming_pairs(nullptr, n_points, idx_left, idx_right, descriptor_left, descriptor_right, distance) != JSORB_OK)
+        throw std::runtime_error("jsorb_hamming_pairs failed");
 }
 
+namespace detail {
+// Binary PGM (P5) / PPM (P6), maxval <= 255 -> gray plane.  For a colour file the conversion is cv::cvtColor(BGR2GRAY)'s 8-bit
+// fixed-point form (R*9798 + G*19235 + B*3735 + 2^14) >> 15; for a gray file it is the identity, as imread(IMREAD_COLOR) followed by
+// BGR2GRAY is (the weights sum to 2^15).
+inline bool read_pnm_gray(const std::string &path, int &w, int &h, std::vector<unsigned char> &gray)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    auto token = [&](int &v) {
+        int c = fgetc(f);
+        while (c == '#' || c == ' ' || c == '\n' || c == '\r' || c == '\t') {
+            if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
+            c = fgetc(f);
+        }
+        v = 0;
+        bool any = false;
+        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = fgetc(f); any = true; }
+        return any;
+    };
+    const int m0 = fgetc(f), m1 = fgetc(f);
+    int maxv = 0;
+    bool ok = m0 == 'P' && (m1 == '5' || m1 == '6') && token(w) && token(h) && token(maxv) && w > 0 && h > 0 && maxv > 0 && maxv <= 255;
+    if (ok) {
+        const int ch = m1 == '6' ? 3 : 1;
+        std::vector<unsigned char> raw((size_t)w * h * ch);
+        ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+        gray.resize((size_t)w * h);
+        for (size_t i = 0; ok && i < gray.size(); i++)
+            gray[i] = ch == 1 ? raw[i] : (unsigned char)((raw[3 * i] * 9798 + raw[3 * i + 1] * 19235 + raw[3 * i + 2] * 3735 + (1 << 14)) >> 15);
+    }
+    fclose(f);
+    return ok;
+}
+} // namespace detail
+
+// orb_cuda::ORB_GPU (include/cuda/orb_gpu.hpp:22-250, src/cuda/orb_gpu.cpp): owns one jsorb handle.  Only the members the reference's
+// untouched host code reaches are recreated.
+class ORB_GPU {
+public:
+    // what Frame::ComputeStereoMatches passes as orb_exl.image_ / orb_exr.image_ (Frame.cpp:799-800): the un-blurred pyramid of the last
+    // extract, which lives inside the handle
+    struct ImagePyramid {
+        ORB_GPU *owner = nullptr;
+        size_t size() const { return owner ? (size_t)jsorb_n_levels(owner->handle_) : 0; }
+        const unsigned char *gpu_data(int level) const { return jsorb_level_image_device(owner->handle_, 0, level, 0); }
+    };
+
+    // argument order of orb_gpu.hpp:26-36
+    ORB_GPU(int im_height, int im_width, int n_levels, float scale_factor, int FAST_N_MIN, int FAST_N_MAX, int th_FAST_MIN, int th_FAST_MAX, int tile_h,
+            int tile_w, bool fixed_multi_scale_tile_size, bool apply_nms_ms, bool nms_ms_mode_gpu, std::string str_mask, int device_id = 0,
+            const unsigned char *mask_plane = nullptr, int max_batch = 1)
+    {
+        std::vector<unsigned char> mask;
+        if (!mask_plane && !str_mask.empty()) {
+            // orb_gpu.cpp:64-75: cv::imread(str_mask); an unreadable file means "no mask" there (mask.empty() -> all 255)
+            int mw = 0, mh = 0;
+            bool have = false;
+#ifdef JSORB_WITH_OPENCV
+            cv::Mat m = cv::imread(str_mask);
+            if (!m.empty()) {
+                cv::cvtColor(m, m, cv::COLOR_BGR2GRAY);
+                mw = m.cols; mh = m.rows;
+                mask.resize((size_t)mw * mh);
+                for (int y = 0; y < mh; y++) memcpy(&mask[(size_t)y * mw], m.ptr(y), mw);
+                have = true;
+            }
+#else
+            have = detail::read_pnm_gray(str_mask, mw, mh, mask);
+            if (!have) {
+                FILE *probe = fopen(str_mask.c_str(), "rb");
+                if (probe) { fclose(probe); throw std::invalid_argument("jsorb: mask file is not a binary PGM/PPM (build with JSORB_WITH_OPENCV for other formats): " + str_mask); }
+            }
+#endif
+            if (have) {
+                // the reference resizes whatever size the mask has to every level (level 0 included) with INTER_NN; the ABI takes the
+                // level-0 plane, so a mask of another size is first brought to level-0 size with the same index rule
+                if (mw != im_width || mh != im_height) {
+                    std::vector<unsigned char> r((size_t)im_width * im_height);
+                    const double ifx = 1.0 / ((double)im_width / mw), ify = 1.0 / ((double)im_height / mh);
+                    for (int y = 0; y < im_height; y++) {
+                        int sy = (int)(y * ify); if (sy > mh - 1) sy = mh - 1;
+                        for (int x = 0; x < im_width; x++) { int sx = (int)(x * ifx); if (sx > mw - 1) sx = mw - 1; r[(size_t)y * im_width + x] = mask[(size_t)sy * mw + sx]; }
+                    }
+                    mask.swap(r);
+                }
+                mask_plane = mask.data();
+            }
+        }
+        jsorb_params p{};
+        p.height = im_height; p.width = im_width; p.n_levels = n_levels; p.scale_factor = scale_factor;
+        p.fast_n_min = FAST_N_MIN; p.fast_n_max = FAST_N_MAX; p.th_fast_min = th_FAST_MIN; p.th_fast_max = th_FAST_MAX;
+        p.tile_h = tile_h; p.tile_w = tile_w; p.fixed_multi_scale_tile_size = fixed_multi_scale_tile_size;
+        p.apply_nms_ms = apply_nms_ms; p.nms_ms_mode_gpu = nms_ms_mode_gpu; p.device_id = device_id; p.max_batch = max_batch;
+        const int rc = jsorb_create(&p, mask_plane, &handle_);
+        if (rc != JSORB_OK) {
+            std::string msg = handle_ ? jsorb_last_error(handle_) : "jsorb_create failed";
+            if (handle_) jsorb_destroy(handle_);
+            handle_ = nullptr;
+            throw std::runtime_error("jsorb_create: " + msg);
+        }
+        n_levels_ = n_levels;
+        for (int i = 0; i < n_levels; i++) {
+            int h = 0, w = 0;
+            jsorb_level_dims(handle_, i, &h, &w, nullptr);
+            height_.push_back(h); width_.push_back(w);
+            scale_.push_back(jsorb_scale(handle_, i)); inv_scale_.push_back(jsorb_inv_scale(handle_, i));
+        }
+        image_.owner = this;
+    }
+    ORB_GPU(const ORB_GPU &) = delete;
+    ORB_GPU &operator=(const ORB_GPU &) = delete;
+    ~ORB_GPU() { if (handle_) jsorb_destroy(handle_); }
+
+    // ORB_GPU::extract (orb_gpu.hpp:40-42, orb_gpu.cpp:489-841), raw-plane form with an explicit row step (the reference assumes
+    // step == width, orb_gpu.cpp:497).  The caller's SyncedMems are resized by the callee and receive the results on BOTH sides: the
+    // device side by a device-to-device copy on the handle's stream, the host side from the handle's pinned mirror.
+    void extract(const unsigned char *image, int step, SyncedMem<int> &out_keypoints, SyncedMem<unsigned char> &out_keypoints_desc)
+    {
+        int n = 0;
+        if (jsorb_extract(handle_, image, step, &n) != JSORB_OK) throw std::runtime_error(std::string("jsorb_extract: ") + jsorb_last_error(handle_));
+        out_keypoints.resize(6 * n);
+        out_keypoints_desc.resize(32 * n);
+        if (n > 0) {
+            void *st = jsorb_get_stream(handle_);
+            int rc = jsorb_mem_d2d_async(out_keypoints.gpu_data_, jsorb_keypoints_device(handle_, 0), (size_t)6 * n * sizeof(int), st);
+            if (rc == JSORB_OK) rc = jsorb_mem_d2d_async(out_keypoints_desc.gpu_data_, jsorb_descriptors_device(handle_, 0), (size_t)32 * n, st);
+            if (rc == JSORB_OK) rc = jsorb_copy_keypoints(handle_, 0, out_keypoints.cpu_data_);
+            if (rc == JSORB_OK) rc = jsorb_copy_descriptors(handle_, 0, out_keypoints_desc.cpu_data_);
+            if (rc == JSORB_OK) rc = jsorb_mem_stream_sync(st);
+            if (rc != JSORB_OK) throw std::runtime_error("jsorb: delivering the extract results failed");
+        }
+        out_keypoints.host_fresh_ = out_keypoints_desc.host_fresh_ = true;
+    }
+#ifdef JSORB_WITH_OPENCV
+    void extract(const cv::Mat &image, SyncedMem<int> &out_keypoints, SyncedMem<unsigned char> &out_keypoints_desc)
+    {
+        extract(image.data, (int)image.step, out_keypoints, out_keypoints_desc);
+    }
+#endif
+
+    // ORB_GPU::ORB_compute_stereo_match (orb_gpu.hpp:218-229, orb_stereo_match.cu:105-580) with the reference's parameter list, so
+    // that Frame::ComputeStereoMatches (Frame.cpp:780-803) compiles unchanged.  It matches the LAST extract of the two handles - which
+    // is what mvKeys / mvKeysRight / the descriptor pointers / the two pyramids describe at that call site; the keypoint vectors are
+    // only used for their sizes (checked), the descriptor pointers are not read.  KeyPoint is cv::KeyPoint in the reference.
+    template <class KeyPoint>
+    void ORB_compute_stereo_match(int ORB_TH_HIGH, int ORB_TH_LOW, float mb, float mbf, std::vector<int> & /*octave_height*/, std::vector<int> & /*octave_width*/,
+                                  std::vector<KeyPoint> &mvKeys, std::vector<KeyPoint> &mvKeysRight, std::vector<float> &mvuRight, std::vector<float> &mvDepth,
+                                  unsigned char * /*descriptor_left_gpu*/, unsigned char * /*descriptor_right_gpu*/, ImagePyramid &images_left,
+                                  ImagePyramid &images_right)
+    {
+        if (images_left.owner != this || !images_right.owner) throw std::invalid_argument("ORB_compute_stereo_match: pyramids do not belong to these extractors");
+        jsorb_extractor *l = handle_, *r = images_right.owner->handle_;
+        const int n = jsorb_n_keypoints(l, 0);
+        if (n < 0 || (size_t)n != mvKeys.size() || (size_t)jsorb_n_keypoints(r, 0) != mvKeysRight.size())
+            throw std::runtime_error("ORB_compute_stereo_match: keypoint vectors do not match the last extract of the handles");
+        mvuRight.resize(mvKeys.size(), -1.0f);          // orb_stereo_match.cu:496-497 (resize keeps earlier contents; the ABI call overwrites all n)
+        mvDepth.resize(mvKeys.size(), -1.0f);
+        float dummy = -1.0f;
+        if (jsorb_stereo_match(l, r, mb, mbf, ORB_TH_HIGH, ORB_TH_LOW, n ? mvuRight.data() : &dummy, n ? mvDepth.data() : &dummy, &last_stereo_stats_) != JSORB_OK)
+            throw std::runtime_error(std::string("jsorb_stereo_match: ") + jsorb_last_error(l));
+    }
+
+    jsorb_extractor *handle() const { return handle_; }
+
+    // public data members of the reference that host code outside ORB_GPU reads (orb_gpu.hpp:240-250; Frame.cpp:784-801)
+    int n_levels_ = 0;
+    std::vector<int> height_, width_;
+    std::vector<float> scale_, inv_scale_;
+    ImagePyramid image_;
+    jsorb_stereo_stats last_stereo_stats_{};
+
+private:
+    jsorb_extractor *handle_ = nullptr;
+};
+
 } // namespace orb_cuda
+
+namespace tracking_cuda {
+// tracking_cuda::compute_isInFrustum_GPU (tracking_gpu.hpp:14-31, tracking_isinfrustum.cu:19-160): synchronous, device pointers
+inline void compute_isInFrustum_GPU(int n_points, float *Px_gpu, float *Py_gpu, float *Pz_gpu, float *Pnx_gpu, float *Pny_gpu, float *Pnz_gpu,
+                                    float *MaxDistance_gpu, float *invariance_maxDistance_gpu, float *invariance_minDistance_gpu, float *Rcw_gpu,
+                                    float *tcw_gpu, float *Ow_gpu, float &fx, float &fy, float &cx, float &cy, int &minX, int &maxX, int &minY, int &maxY,
+                                    int &nScaleLevels, float &logScaleFactor, float &viewCosAngle, float *invz_gpu, float *u_gpu, float *v_gpu,
+                                    int *predictedlevel_gpu, float *viewCos_gpu, unsigned char *is_infrustum_gpu)
+{
+    if (jsorb_is_in_frustum(nullptr, n_points, Px_gpu, Py_gpu, Pz_gpu, Pnx_gpu, Pny_gpu, Pnz_gpu, MaxDistance_gpu, invariance_maxDistance_gpu,
+                            invariance_minDistance_gpu, Rcw_gpu, tcw_gpu, Ow_gpu, fx, fy, cx, cy, minX, maxX, minY, maxY, nScaleLevels, logScaleFactor,
+                            viewCosAngle, invz_gpu, u_gpu, v_gpu, predictedlevel_gpu, viewCos_gpu, is_infrustum_gpu) != JSORB_OK)
+        throw std::runtime_error("jsorb_is_in_frustum failed");
+}
+} // namespace tracking_cuda
 
 namespace Jetson_SLAM {
 
@@ -60,59 +355,36 @@ using orb_cuda::SyncedMem;
 
 class ORBExtractor {
 public:
-    // argument order of include/ORBextractor.h:25-35; str_mask: "" = no mask.  A mask image has to be decoded by the caller
-    // (the reference uses cv::imread) and passed through set-up code as a raw plane via the second constructor.
+    // argument order of include/ORBextractor.h:25-35; str_mask: "" = no mask, else an image file (see ORB_GPU above)
     ORBExtractor(int im_height, int im_width, float scale_factor, int n_levels, int FAST_N_MIN, int FAST_N_MAX, int th_FAST_MIN,
                  int th_FAST_MAX, std::string str_mask, int tile_h, int tile_w, bool fixed_multi_scale_tile_size, bool apply_nms_ms,
                  bool nms_ms_mode_gpu, bool use_gpu = false)
-        : ORBExtractor(im_height, im_width, scale_factor, n_levels, FAST_N_MIN, FAST_N_MAX, th_FAST_MIN, th_FAST_MAX,
-                       (const unsigned char *)nullptr, tile_h, tile_w, fixed_multi_scale_tile_size, apply_nms_ms, nms_ms_mode_gpu, use_gpu)
     {
-        if (!str_mask.empty()) throw std::invalid_argument("jsorb: pass the decoded mask plane instead of a file name");
+        init(im_height, im_width, scale_factor, n_levels, use_gpu);
+        // src/ORBextractor.cpp:75-87 (the GPU object is built whatever use_gpu says; device 0)
+        orb_gpu_ = new orb_cuda::ORB_GPU(im_height, im_width, n_levels, scale_factor, FAST_N_MIN, FAST_N_MAX, th_FAST_MIN, th_FAST_MAX, tile_h, tile_w,
+                                         fixed_multi_scale_tile_size, apply_nms_ms, nms_ms_mode_gpu, str_mask, 0);
     }
-
+    // additions: the mask as a decoded level-0 plane (NULL = none), an explicit device, a batch capacity
     ORBExtractor(int im_height, int im_width, float scale_factor, int n_levels, int FAST_N_MIN, int FAST_N_MAX, int th_FAST_MIN,
                  int th_FAST_MAX, const unsigned char *mask_plane, int tile_h, int tile_w, bool fixed_multi_scale_tile_size,
-                 bool apply_nms_ms, bool nms_ms_mode_gpu, bool /*use_gpu*/ = false, int device_id = 0)
+                 bool apply_nms_ms, bool nms_ms_mode_gpu, bool use_gpu = false, int device_id = 0, int max_batch = 1)
     {
-        n_levels_ = n_levels;
-        scale_factor_ = scale_factor;
-        // src/ORBextractor.cpp:43-71
-        scale_.resize(n_levels); inv_scale_.resize(n_levels); level_sigma2_.resize(n_levels); inv_level_sigma2_.resize(n_levels);
-        scale_[0] = 1.0f; level_sigma2_[0] = 1.0f;
-        for (int i = 1; i < n_levels; i++) { scale_[i] = scale_[i - 1] * scale_factor_; level_sigma2_[i] = scale_[i] * scale_[i]; }
-        for (int i = 0; i < n_levels; i++) { inv_scale_[i] = 1.0f / scale_[i]; inv_level_sigma2_[i] = 1.0f / level_sigma2_[i]; }
-        jsorb_params p{};
-        p.height = im_height; p.width = im_width; p.n_levels = n_levels; p.scale_factor = scale_factor;
-        p.fast_n_min = FAST_N_MIN; p.fast_n_max = FAST_N_MAX; p.th_fast_min = th_FAST_MIN; p.th_fast_max = th_FAST_MAX;
-        p.tile_h = tile_h; p.tile_w = tile_w; p.fixed_multi_scale_tile_size = fixed_multi_scale_tile_size;
-        p.apply_nms_ms = apply_nms_ms; p.nms_ms_mode_gpu = nms_ms_mode_gpu; p.device_id = device_id; p.max_batch = 1;
-        const int rc = jsorb_create(&p, mask_plane, &orb_gpu_);
-        if (rc != JSORB_OK) {
-            std::string msg = orb_gpu_ ? jsorb_last_error(orb_gpu_) : "jsorb_create failed";
-            if (orb_gpu_) jsorb_destroy(orb_gpu_);
-            orb_gpu_ = nullptr;
-            throw std::runtime_error("jsorb_create: " + msg);
-        }
-        width_ = im_width; height_ = im_height;
+        init(im_height, im_width, scale_factor, n_levels, use_gpu);
+        orb_gpu_ = new orb_cuda::ORB_GPU(im_height, im_width, n_levels, scale_factor, FAST_N_MIN, FAST_N_MAX, th_FAST_MIN, th_FAST_MAX, tile_h, tile_w,
+                                         fixed_multi_scale_tile_size, apply_nms_ms, nms_ms_mode_gpu, std::string(), device_id, mask_plane, max_batch);
     }
     ORBExtractor(const ORBExtractor &) = delete;
     ORBExtractor &operator=(const ORBExtractor &) = delete;
-    ~ORBExtractor() { if (orb_gpu_) jsorb_destroy(orb_gpu_); }
+    ~ORBExtractor() { delete orb_gpu_; }
 
     // raw-plane form of extract(const cv::Mat&, SyncedMem<int>&, SyncedMem<unsigned char>&)  (ORBextractor.h:40-42)
     void extract(const unsigned char *image, int step, SyncedMem<int> &keypoints, SyncedMem<unsigned char> &keypoints_desc)
     {
-        int n = 0;
-        if (jsorb_extract(orb_gpu_, image, step, &n) != JSORB_OK) throw std::runtime_error(std::string("jsorb_extract: ") + jsorb_last_error(orb_gpu_));
-        keypoints.resize(6 * n); keypoints.gpu_data_ = jsorb_keypoints_device(orb_gpu_, 0); keypoints.owner_ = orb_gpu_; keypoints.image_ = 0;
-        keypoints_desc.resize(32 * n); keypoints_desc.gpu_data_ = jsorb_descriptors_device(orb_gpu_, 0); keypoints_desc.owner_ = orb_gpu_; keypoints_desc.image_ = 0;
+        orb_gpu_->extract(image, step, keypoints, keypoints_desc);
     }
 #ifdef JSORB_WITH_OPENCV
-    void extract(const cv::Mat &image, SyncedMem<int> &keypoints, SyncedMem<unsigned char> &keypoints_desc)
-    {
-        extract(image.data, (int)image.step, keypoints, keypoints_desc);   // explicit step (the reference assumes step == width, orb_gpu.cpp:497)
-    }
+    void extract(const cv::Mat &image, SyncedMem<int> &keypoints, SyncedMem<unsigned char> &keypoints_desc) { orb_gpu_->extract(image, keypoints, keypoints_desc); }
     void operator()(const cv::Mat &image, SyncedMem<int> &k, SyncedMem<unsigned char> &d) { extract(image, k, d); }
 #endif
 
@@ -123,51 +395,65 @@ public:
     std::vector<float> get_scale_sigma_squares() { return level_sigma2_; }
     std::vector<float> get_inverse_scale_sigma_squares() { return inv_level_sigma2_; }
 
-    jsorb_extractor *orb_gpu_ = nullptr;   // the reference exposes its ORB_GPU* under this name (ORBextractor.h:75)
+    orb_cuda::ORB_GPU *orb_gpu_ = nullptr;   // ORBextractor.h:75
+    jsorb_extractor *handle() const { return orb_gpu_->handle(); }
 
 protected:
+    void init(int im_height, int im_width, float scale_factor, int n_levels, bool use_gpu)
+    {
+        n_levels_ = n_levels;
+        scale_factor_ = scale_factor;
+        use_gpu_ = use_gpu;
+        // src/ORBextractor.cpp:43-71
+        scale_.resize(n_levels); inv_scale_.resize(n_levels); level_sigma2_.resize(n_levels); inv_level_sigma2_.resize(n_levels);
+        scale_[0] = 1.0f; level_sigma2_[0] = 1.0f;
+        for (int i = 1; i < n_levels; i++) { scale_[i] = scale_[i - 1] * scale_factor_; level_sigma2_[i] = scale_[i] * scale_[i]; }
+        for (int i = 0; i < n_levels; i++) { inv_scale_[i] = 1.0f / scale_[i]; inv_level_sigma2_[i] = 1.0f / level_sigma2_[i]; }
+        width_.assign(1, im_width); height_.assign(1, im_height);
+    }
+    std::vector<int> height_, width_;
     std::vector<float> scale_, inv_scale_, level_sigma2_, inv_level_sigma2_;
-    int n_levels_ = 0, width_ = 0, height_ = 0;
+    int n_levels_ = 0;
     float scale_factor_ = 1.f;
+    bool use_gpu_ = false;
 };
 
-// Body of Frame::ComputeStereoMatches (Frame.cpp:780-803): mvuRight / mvDepth sized N_left, -1 = no match.
-// TH_HIGH / TH_LOW are ORBmatcher's (ORBmatcher.cpp:24-25).  mb must be mbf/fx (the reference reads an unassigned
-// Frame::mb here on a fresh Frame, Frame.cpp:219 vs :247).
+// Free-function form of Frame::ComputeStereoMatches (Frame.cpp:780-803): mvuRight / mvDepth sized N_left, -1 = no match.
+// TH_HIGH / TH_LOW are ORBmatcher's (ORBmatcher.cpp:24-25).  mb must be mbf/fx (the reference reads an unassigned Frame::mb here on a
+// fresh Frame, Frame.cpp:219 vs :247).
 inline void ComputeStereoMatches(ORBExtractor &left, ORBExtractor &right, float mb, float mbf, std::vector<float> &mvuRight,
                                  std::vector<float> &mvDepth, jsorb_stereo_stats *stats = nullptr, int TH_HIGH = 100, int TH_LOW = 50)
 {
-    const int n = jsorb_n_keypoints(left.orb_gpu_, 0);
+    const int n = jsorb_n_keypoints(left.handle(), 0);
     if (n < 0) throw std::runtime_error("ComputeStereoMatches before extract");
     mvuRight.assign(n, -1.0f);
     mvDepth.assign(n, -1.0f);
     float dummy = -1.0f;
-    const int rc = jsorb_stereo_match(left.orb_gpu_, right.orb_gpu_, mb, mbf, TH_HIGH, TH_LOW, n ? mvuRight.data() : &dummy, n ? mvDepth.data() : &dummy, stats);
-    if (rc != JSORB_OK) throw std::runtime_error(std::string("jsorb_stereo_match: ") + jsorb_last_error(left.orb_gpu_));
+    const int rc = jsorb_stereo_match(left.handle(), right.handle(), mb, mbf, TH_HIGH, TH_LOW, n ? mvuRight.data() : &dummy, n ? mvDepth.data() : &dummy, stats);
+    if (rc != JSORB_OK) throw std::runtime_error(std::string("jsorb_stereo_match: ") + jsorb_last_error(left.handle()));
 }
 
 // Body of the keypoint / descriptor unpacking of Frame::Frame (Frame.cpp:119-196) for one image: mvKeys-shaped records (the
-// memory layout of cv::KeyPoint) and the N x 32 descriptor rows, produced on the device and fetched with one synchronisation
-// instead of SyncedMem::to_cpu() x 2 + a host loop.
+// memory layout of cv::KeyPoint) and the N x 32 descriptor rows.
 inline void UnpackFrame(ORBExtractor &ex, std::vector<jsorb_keypoint> &keys, std::vector<unsigned char> &descriptors)
 {
-    const int n = jsorb_n_keypoints(ex.orb_gpu_, 0);
+    const int n = jsorb_n_keypoints(ex.handle(), 0);
     if (n < 0) throw std::runtime_error("UnpackFrame before extract");
     keys.resize(n);
     descriptors.resize((size_t)32 * n);
-    if (n && jsorb_unpack_frame(ex.orb_gpu_, 0, keys.data(), descriptors.data()) != JSORB_OK)
-        throw std::runtime_error(std::string("jsorb_unpack_frame: ") + jsorb_last_error(ex.orb_gpu_));
+    if (n && jsorb_unpack_frame(ex.handle(), 0, keys.data(), descriptors.data()) != JSORB_OK)
+        throw std::runtime_error(std::string("jsorb_unpack_frame: ") + jsorb_last_error(ex.handle()));
 }
 #ifdef JSORB_WITH_OPENCV
 inline void UnpackFrame(ORBExtractor &ex, std::vector<cv::KeyPoint> &mvKeys, cv::Mat &mDescriptors)
 {
     static_assert(sizeof(cv::KeyPoint) == sizeof(jsorb_keypoint), "jsorb_keypoint mirrors cv::KeyPoint");
-    const int n = jsorb_n_keypoints(ex.orb_gpu_, 0);
+    const int n = jsorb_n_keypoints(ex.handle(), 0);
     if (n < 0) throw std::runtime_error("UnpackFrame before extract");
     mvKeys.resize(n);
     mDescriptors = cv::Mat(n, 32, CV_8UC1);
-    if (n && jsorb_unpack_frame(ex.orb_gpu_, 0, reinterpret_cast<jsorb_keypoint *>(mvKeys.data()), mDescriptors.data) != JSORB_OK)
-        throw std::runtime_error(std::string("jsorb_unpack_frame: ") + jsorb_last_error(ex.orb_gpu_));
+    if (n && jsorb_unpack_frame(ex.handle(), 0, reinterpret_cast<jsorb_keypoint *>(mvKeys.data()), mDescriptors.data) != JSORB_OK)
+        throw std::runtime_error(std::string("jsorb_unpack_frame: ") + jsorb_last_error(ex.handle()));
 }
 #endif
 
@@ -177,12 +463,12 @@ template <std::size_t COLS, std::size_t ROWS>
 inline void AssignFeaturesToGrid(ORBExtractor &ex, float mnMinX, float mnMinY, float mfGridElementWidthInv, float mfGridElementHeightInv,
                                  std::vector<std::size_t> (&mGrid)[COLS][ROWS])
 {
-    const int n = jsorb_n_keypoints(ex.orb_gpu_, 0);
+    const int n = jsorb_n_keypoints(ex.handle(), 0);
     if (n < 0) throw std::runtime_error("AssignFeaturesToGrid before extract");
     std::vector<int32_t> start(COLS * ROWS + 1), items(n > 0 ? n : 1);
-    if (jsorb_assign_features_to_grid(ex.orb_gpu_, 0, mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv, (int)COLS, (int)ROWS,
+    if (jsorb_assign_features_to_grid(ex.handle(), 0, mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv, (int)COLS, (int)ROWS,
                                       start.data(), items.data()) != JSORB_OK)
-        throw std::runtime_error(std::string("jsorb_assign_features_to_grid: ") + jsorb_last_error(ex.orb_gpu_));
+        throw std::runtime_error(std::string("jsorb_assign_features_to_grid: ") + jsorb_last_error(ex.handle()));
     for (std::size_t i = 0; i < COLS; i++)
         for (std::size_t j = 0; j < ROWS; j++) {
             const std::size_t c = i * ROWS + j;

@@ -20,6 +20,8 @@
 #include "../../include/jsorb.h"
 #include "jsorb_launch.h"
 
+#define JSORB_MAX_LANES 4
+
 using namespace jsorb;
 
 namespace {
@@ -37,9 +39,21 @@ struct jsorb_extractor {
     int n_images = 0;          // images of the last extract
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t done = nullptr;         // recorded after the last enqueued work of this handle
-    hipEvent_t readers_done = nullptr; // recorded on ANOTHER handle's stream after it finished reading this handle's buffers
+    // Lanes: a batch of many images is split into up to JSORB_MAX_LANES contiguous sub-batches, each enqueued on its own HIP stream
+    // (lane 0 = `stream`, the handle's main / caller-provided stream).  The sparse, latency-bound stages of one lane (FAST ring
+    // test / NMS, descriptor gathers, the single-workgroup compaction and median kernels) then overlap the streaming stages of
+    // another one.  A single frame (the reference's call shape) uses lane 0 only.
+    hipStream_t lane_own[JSORB_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_done[JSORB_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};          // after the last work enqueued on lane j
+    hipEvent_t lane_readers_done[JSORB_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};  // recorded on ANOTHER handle's lanes after they read this handle's buffers
+    hipEvent_t ev_fork = nullptr;
+    int max_lanes = JSORB_MAX_LANES;
+    int K = 1;                 // lanes used by the last batch
+    int lane_first[JSORB_MAX_LANES + 1] = {0, 0, 0, 0, 0};
     bool has_readers = false;
+    int readers_K = 0, readers_n = 0;
+    bool counts_synced = false;        // h_counts / h_stats reflect the last enqueued batch (set by jsorb_sync)
+    bool counts_synced_before_stereo = false;
     size_t detect_lds = 0, pyr_lds = 0;
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
@@ -47,8 +61,9 @@ struct jsorb_extractor {
     // in place as level 0.  Double buffering lets the upload of batch k+1 overlap the kernels of batch k.
     uint8_t *stage[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-    bool consumed_valid[2] = {false, false};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_consumed[2][JSORB_MAX_LANES] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per landing buffer and lane
+    int consumed_K[2] = {0, 0};        // lanes whose ev_consumed must be waited for before the buffer is refilled (0: never used)
     int stage_cur = 0, last_stage = -1;
     uint32_t *lut_bits = nullptr;
     unsigned long long *tile_out = nullptr, *kp = nullptr;
@@ -254,7 +269,7 @@ int enqueue_timed(jsorb_extractor *e, int id)
     TimedLaunch t{id, nullptr, nullptr};
     HIPCHK(e, hipEventCreate(&t.a));
     HIPCHK(e, hipEventCreate(&t.b));
-    HIPCHK(e, hipEventRecord(t.a, e->stream));
+    HIPCHK(e, hipEventRecord(t.a, e->stream));          // timing forces one lane: everything runs on the main stream
     e->timed.push_back(t);
     return JSORB_OK;
 }
@@ -288,25 +303,87 @@ int drain_timed(jsorb_extractor *e)
         if (_rc) return _rc;                                 \
     } while (0)
 
-int run_pipeline(jsorb_extractor *e, int n)
+inline hipStream_t lane_stream(const jsorb_extractor *e, int j) { return j == 0 ? e->stream : e->lane_own[j]; }
+
+// Split n images into contiguous lanes.  A lane keeps at least ~7 Mpx of level-0 pixels (about 20 images of 752x480) so that each
+// launch still fills the 256 CUs; per-kernel timing (which serialises launches anyway) and small batches use one lane.
+int plan_lanes(const jsorb_extractor *e, int n, int *first)
 {
-    const Geometry &g = e->g;
-    if (e->has_readers) {   // a stereo match enqueued on the other handle's stream may still read our previous results
-        HIPCHK(e, hipStreamWaitEvent(e->stream, e->readers_done, 0));
+    const double px = (double)e->g.lv[0].H * e->g.lv[0].W;
+    const int min_per_lane = std::max(1, (int)std::ceil(7.0e6 / px));
+    int K = std::min(e->max_lanes, n / min_per_lane);
+    if (K < 1 || e->timing) K = 1;
+    const int base = n / K, rem = n % K;
+    first[0] = 0;
+    for (int j = 0; j < K; j++) first[j + 1] = first[j] + base + (j < rem ? 1 : 0);
+    return K;
+}
+
+// Orders the lanes of a NEW batch (K lanes over n images) after everything that touched the handle's buffers before:
+//  * work the caller (or this handle) enqueued on the main stream: lanes >= 1 wait for a fork event recorded on lane 0
+//  * the previous batch of this handle, when its lane partition differs (same partition: same-stream order is enough)
+//  * a stereo match enqueued on ANOTHER handle's lanes that may still read this handle's previous results
+//  * `input_ready` (optional): e.g. the upload of this batch on the copy stream
+int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, hipEvent_t input_ready)
+{
+    if (K > 1) {
+        HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
+        for (int j = 1; j < K; j++) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->ev_fork, 0));
+    }
+    const bool same = e->extracted && K == e->K && n == e->n_images;
+    if (e->extracted && !same)
+        for (int j = 0; j < K; j++)
+            for (int i = 0; i < e->K; i++)
+                if (i != j) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->lane_done[i], 0));
+    if (e->has_readers) {
+        const bool aligned = e->readers_K == K && e->readers_n == n;
+        for (int j = 0; j < K; j++) {
+            if (aligned) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->lane_readers_done[j], 0));
+            else
+                for (int i = 0; i < e->readers_K; i++) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->lane_readers_done[i], 0));
+        }
         e->has_readers = false;
     }
-    TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, e->src, e->slab, e->lut_bits, n, e->pyr_lds, e->stream));
-    TIMED(e, JSORB_K_DETECT, launch_detect(g, e->src, e->slab, e->mask, e->lut_bits, e->tile_out, n, e->detect_lds, e->stream));
-    if (e->nms_ms) TIMED(e, JSORB_K_NMS_MS, launch_nms_ms(g, e->tile_out, e->ms_grid, e->ms_scratch, e->p.nms_ms_mode_gpu, n, e->stream));
-    TIMED(e, JSORB_K_COMPACT, launch_compact(g, e->tile_out, e->kp, e->counts, e->row_tab, n, e->stream));
-    TIMED(e, JSORB_K_BLUR, launch_blur(g, e->src, e->slab, e->blur, e->lut_bits, n, e->stream));
-    TIMED(e, JSORB_K_DESCRIBE, launch_describe(g, e->src, e->slab, e->blur, e->kp, e->counts, e->angles, e->desc, e->out_kp, n, e->stream));
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipMemcpyAsync(e->h_counts, e->counts, sizeof(int) * (JSORB_MAX_LEVELS + 1) * n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipEventRecord(e->done, e->stream));
+    if (input_ready)
+        for (int j = 0; j < K; j++) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), input_ready, 0));
+    return JSORB_OK;
+}
+
+int run_pipeline(jsorb_extractor *e, int n, hipEvent_t input_ready = nullptr)
+{
+    const Geometry &g = e->g;
+    int first[JSORB_MAX_LANES + 1];
+    const int K = plan_lanes(e, n, first);
+    int rc = order_lanes_for_new_batch(e, K, n, input_ready);
+    if (rc) return rc;
+    const size_t T = (size_t)g.T;
+    const int CW = JSORB_MAX_LEVELS + 1;
+    for (int j = 0; j < K; j++) {
+        const int f = first[j], m = first[j + 1] - f;
+        hipStream_t st = lane_stream(e, j);
+        ImageSrc src = e->src;
+        src.l0 += (size_t)f * src.l0_stride;
+        uint8_t *slab = e->slab + (size_t)f * g.slab_bytes, *blur = e->blur + (size_t)f * g.slab_bytes;
+        unsigned long long *tile_out = e->tile_out + f * T, *kp = e->kp + f * T;
+        int *counts = e->counts + f * CW;
+        TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
+        TIMED(e, JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
+        if (e->nms_ms)
+            TIMED(e, JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
+                                                   e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
+        TIMED(e, JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st));
+        TIMED(e, JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
+        TIMED(e, JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st));
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipMemcpyAsync(e->h_counts + f * CW, counts, sizeof(int) * CW * m, hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipEventRecord(e->lane_done[j], st));
+    }
+    e->K = K;
+    for (int j = 0; j <= K; j++) e->lane_first[j] = first[j];
     e->n_images = n;
     e->extracted = true;
     e->stereo_done = false;
+    e->counts_synced = false;
     return JSORB_OK;
 }
 
@@ -341,8 +418,13 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
-    HIPCHK(e, hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
-    HIPCHK(e, hipEventCreateWithFlags(&e->readers_done, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int j = 0; j < JSORB_MAX_LANES; j++) {
+        if (j > 0) HIPCHK(e, hipStreamCreateWithFlags(&e->lane_own[j], hipStreamNonBlocking));
+        HIPCHK(e, hipEventCreateWithFlags(&e->lane_done[j], hipEventDisableTiming));
+        HIPCHK(e, hipEventCreateWithFlags(&e->lane_readers_done[j], hipEventDisableTiming));
+    }
+    if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));
     for (int i = 0; i < g.L; i++) {                        // needed by the LDS layout: the arg-max form needs 256 B where the literal tree needs 1 KB
         uint8_t tr[256];
         g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !getenv("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
@@ -363,7 +445,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         for (int k = 0; k < 2; k++) {
             HIPCHK(e, hipMalloc(&e->stage[k], B * (size_t)g.lv[0].H * g.lv[0].W + 256));
             HIPCHK(e, hipEventCreateWithFlags(&e->ev_copied[k], hipEventDisableTiming));
-            HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k], hipEventDisableTiming));
+            for (int j = 0; j < JSORB_MAX_LANES; j++) HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k][j], hipEventDisableTiming));
         }
     }
     HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
@@ -433,17 +515,17 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         HIPCHK(e, hipMemcpy(e->lut_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (mask) {
-        // orb_gpu.cpp:64-91: nearest-neighbour resample per level, then threshold (>10 -> 255).  OpenCV is not available; the
-        // definition adopted is src = min(floor(dst*src_size/dst_size), src_size-1) - parity with OpenCV's INTER_NN is unpinned.
+        // orb_gpu.cpp:77-81: cv::resize(..., CV_INTER_NN) per level, then threshold (>10 -> 255).  The source index is OpenCV's
+        // resizeNN one: ifx = 1./(dst/(double)src), sx = min(cvFloor(x*ifx), src-1) - NOT floor(x*src/dst), which differs on
+        // exact-integer quotients (752->626 column 313, 480->231 rows 77 and 154, ...).
         std::vector<uint8_t> m(g.slab_bytes, 0);
         for (int i = 0; i < g.L; i++) {
             const LevelDesc &lv = g.lv[i];
+            const double ifx = 1.0 / ((double)lv.W / (double)g.lv[0].W), ify = 1.0 / ((double)lv.H / (double)g.lv[0].H);
             for (int y = 0; y < lv.H; y++) {
-                int sy = (int)std::floor((double)y * g.lv[0].H / lv.H);
-                if (sy > g.lv[0].H - 1) sy = g.lv[0].H - 1;
+                const int sy = std::min((int)std::floor((double)y * ify), g.lv[0].H - 1);
                 for (int x = 0; x < lv.W; x++) {
-                    int sx = (int)std::floor((double)x * g.lv[0].W / lv.W);
-                    if (sx > g.lv[0].W - 1) sx = g.lv[0].W - 1;
+                    const int sx = std::min((int)std::floor((double)x * ifx), g.lv[0].W - 1);
                     m[lv.img_off + (size_t)y * lv.pitch + x] = mask[(size_t)sy * g.lv[0].W + sx] > 10 ? 255 : 0;
                 }
             }
@@ -460,6 +542,8 @@ void jsorb_destroy(jsorb_extractor *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    for (int j = 1; j < JSORB_MAX_LANES; j++)
+        if (e->lane_own[j]) (void)hipStreamSynchronize(e->lane_own[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
                     e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
@@ -469,11 +553,16 @@ void jsorb_destroy(jsorb_extractor *e)
     for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d})
         if (hp) (void)hipHostFree(hp);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
-    if (e->done) (void)hipEventDestroy(e->done);
-    if (e->readers_done) (void)hipEventDestroy(e->readers_done);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int j = 0; j < JSORB_MAX_LANES; j++) {
+        if (e->lane_done[j]) (void)hipEventDestroy(e->lane_done[j]);
+        if (e->lane_readers_done[j]) (void)hipEventDestroy(e->lane_readers_done[j]);
+        if (e->lane_own[j]) (void)hipStreamDestroy(e->lane_own[j]);
+    }
     for (int k = 0; k < 2; k++) {
         if (e->ev_copied[k]) (void)hipEventDestroy(e->ev_copied[k]);
-        if (e->ev_consumed[k]) (void)hipEventDestroy(e->ev_consumed[k]);
+        for (int j = 0; j < JSORB_MAX_LANES; j++)
+            if (e->ev_consumed[k][j]) (void)hipEventDestroy(e->ev_consumed[k][j]);
     }
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -483,7 +572,12 @@ void jsorb_destroy(jsorb_extractor *e)
 int jsorb_set_stream(jsorb_extractor *e, void *hip_stream)
 {
     if (!e) return JSORB_ERR_INVALID;
-    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    hipStream_t ns = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    if (ns != e->stream && e->extracted) {      // the new main stream continues after whatever the old one (and the lanes) were doing
+        HIPCHK(e, hipSetDevice(e->device));
+        for (int j = 0; j < e->K; j++) HIPCHK(e, hipStreamWaitEvent(ns, e->lane_done[j], 0));
+    }
+    e->stream = ns;
     return JSORB_OK;
 }
 void *jsorb_get_stream(const jsorb_extractor *e) { return e ? (void *)e->stream : nullptr; }
@@ -492,7 +586,8 @@ int jsorb_stream_wait_done(jsorb_extractor *e, void *other)
 {
     if (!e) return JSORB_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
-    if ((hipStream_t)other != e->stream) HIPCHK(e, hipStreamWaitEvent((hipStream_t)other, e->done, 0));
+    for (int j = 0; j < e->K; j++)
+        if ((hipStream_t)other != lane_stream(e, j)) HIPCHK(e, hipStreamWaitEvent((hipStream_t)other, e->lane_done[j], 0));
     return JSORB_OK;
 }
 
@@ -500,8 +595,34 @@ int jsorb_sync(jsorb_extractor *e)
 {
     if (!e) return JSORB_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (int j = 0; j < e->K; j++) HIPCHK(e, hipStreamSynchronize(lane_stream(e, j)));
+    e->counts_synced = true;
     return drain_timed(e);
+}
+
+// Copies into the level-0 plane of the internal slab are enqueued on the main stream BEFORE the lanes of the new batch are ordered:
+// the main stream first has to wait for whoever may still read the slab (other lanes of the previous batch, a stereo match).
+static int join_previous_on_main(jsorb_extractor *e)
+{
+    if (e->extracted)
+        for (int i = 1; i < e->K; i++) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_done[i], 0));
+    if (e->has_readers)
+        for (int i = 0; i < e->readers_K; i++) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_readers_done[i], 0));
+    return JSORB_OK;
+}
+
+// A landing buffer may be refilled only after every lane that read it in place (extract kernels and, if any, the stereo match)
+static int wait_buffer_consumed(jsorb_extractor *e, int k, hipStream_t s)
+{
+    for (int j = 0; j < e->consumed_K[k]; j++) HIPCHK(e, hipStreamWaitEvent(s, e->ev_consumed[k][j], 0));
+    return JSORB_OK;
+}
+static int mark_buffer_consumed(jsorb_extractor *e, int k)
+{
+    for (int j = 0; j < e->K; j++) HIPCHK(e, hipEventRecord(e->ev_consumed[k][j], lane_stream(e, j)));
+    e->consumed_K[k] = e->K;
+    e->last_stage = k;
+    return JSORB_OK;
 }
 
 int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
@@ -511,41 +632,35 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
     const size_t img_bytes = (size_t)l0.H * l0.W;
+    int rc;
     if (e->stage[0] && step == l0.W && n_images == 1) {
-        // single frame (the reference-shaped call): lowest latency - upload on the compute stream itself, no cross-stream hops
-        if (e->has_readers) {   // the previous stereo match (enqueued on the other handle's stream) read this buffer in place
-            HIPCHK(e, hipStreamWaitEvent(e->stream, e->readers_done, 0));
-            e->has_readers = false;
-        }
+        // single frame (the reference-shaped call): lowest latency - upload on the compute stream itself, no cross-stream hops.
+        // The buffer may still be read by an earlier batch on other lanes / by a stereo match on the other handle's stream.
+        if ((rc = wait_buffer_consumed(e, 0, e->stream))) return rc;
+        if ((rc = join_previous_on_main(e))) return rc;
         HIPCHK(e, hipMemcpyAsync(e->stage[0], host_images, img_bytes, hipMemcpyHostToDevice, e->stream));
         e->src.l0 = e->stage[0]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
-        e->last_stage = -1;
-        e->consumed_valid[0] = false;
+        if ((rc = run_pipeline(e, n_images))) return rc;
         e->stage_cur = 1;       // a following batch call starts on the other buffer
-        return run_pipeline(e, n_images);
+        return mark_buffer_consumed(e, 0);
     }
     if (e->stage[0] && step == l0.W && image_stride == img_bytes) {
         // dense batch: ONE pinned hipMemcpyAsync for all images on the copy stream, then level 0 is read in place from the landing
         // buffer.  The buffer being refilled was last read two batches ago (its extract kernels and, if any, the stereo match).
         const int k = e->stage_cur;
-        if (e->consumed_valid[k]) HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->ev_consumed[k], 0));
+        if ((rc = wait_buffer_consumed(e, k, e->copy_stream))) return rc;
         HIPCHK(e, hipMemcpyAsync(e->stage[k], host_images, img_bytes * n_images, hipMemcpyHostToDevice, e->copy_stream));
         HIPCHK(e, hipEventRecord(e->ev_copied[k], e->copy_stream));
-        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_copied[k], 0));
         e->src.l0 = e->stage[k]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
-        const int rc = run_pipeline(e, n_images);
-        if (rc) return rc;
-        HIPCHK(e, hipEventRecord(e->ev_consumed[k], e->stream));
-        e->consumed_valid[k] = true;
-        e->last_stage = k;
+        if ((rc = run_pipeline(e, n_images, e->ev_copied[k]))) return rc;
         e->stage_cur = k ^ 1;
-        return JSORB_OK;
-    } else {
-        for (int i = 0; i < n_images; i++)   // strided input: one 2-D copy per image into the pitched slab
-            HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
-                                       l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
-        e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
+        return mark_buffer_consumed(e, k);
     }
+    if ((rc = join_previous_on_main(e))) return rc;
+    for (int i = 0; i < n_images; i++)   // strided input: one 2-D copy per image into the pitched slab (main stream; the lanes fork after it)
+        HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
+                                   l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
+    e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
     e->last_stage = -1;
     return run_pipeline(e, n_images);
 }
@@ -560,6 +675,8 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     if (in_place) {   // level 0 is read where it lies: no copy of the grayscale plane
         e->src.l0 = dev_images; e->src.l0_stride = image_stride; e->src.l0_pitch = step;
     } else {
+        const int rc = join_previous_on_main(e);
+        if (rc) return rc;
         for (int i = 0; i < n_images; i++)
             HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, dev_images + (size_t)i * image_stride, step,
                                        l0.W, l0.H, hipMemcpyDeviceToDevice, e->stream));
@@ -734,6 +851,14 @@ int jsorb_copy_level_image(const jsorb_extractor *e, int image, int level, int b
     const int pitch = (!blurred && level == 0) ? e->src.l0_pitch : lv.pitch;
     return hipMemcpy2D(dst, lv.W, p, pitch, lv.W, lv.H, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
 }
+int jsorb_copy_level_mask(const jsorb_extractor *e, int level, uint8_t *dst)
+{
+    if (!e || !dst || level < 0 || level >= e->g.L) return JSORB_ERR_INVALID;
+    const LevelDesc &lv = e->g.lv[level];
+    if (!e->mask) { memset(dst, 255, (size_t)lv.H * lv.W); return JSORB_OK; }
+    if (hipSetDevice(e->device) != hipSuccess) return JSORB_ERR_HIP;
+    return hipMemcpy2D(dst, lv.W, e->mask + lv.img_off, lv.pitch, lv.W, lv.H, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
 int jsorb_copy_tile_candidates(const jsorb_extractor *e, int image, int32_t *x, int32_t *y, int32_t *score)
 {
     if (!check_image(e, image)) return JSORB_ERR_STATE;
@@ -764,29 +889,55 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     }
     HIPCHK(l, hipSetDevice(l->device));
     const int n = l->n_images;
-    if (r->stream != l->stream) HIPCHK(l, hipStreamWaitEvent(l->stream, r->done, 0));
     StereoArgs sa;
     sa.maxD = mbf / mb;                  // const float maxD = mbf/minZ  (orb_stereo_match.cu:144-146)
     sa.mbf = mbf;
     sa.th_high = th_high;
     sa.th_orb = (th_high + th_low) / 2;
-    HIPCHK(l, hipMemsetAsync(l->st_stats, 0, sizeof(int) * 8 * n, l->stream));
-    TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts,
-                                          r->desc, r->row_tab, l->st_u, l->st_d, l->st_l1, l->st_aux, sa, n, l->stream));
-    TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts, l->st_u, l->st_d, l->st_l1, l->st_aux, l->st_stats, n, l->stream));
-    HIPCHK(l, hipGetLastError());
-    HIPCHK(l, hipMemcpyAsync(l->h_stats, l->st_stats, sizeof(int) * 8 * n, hipMemcpyDeviceToHost, l->stream));
-    HIPCHK(l, hipEventRecord(l->done, l->stream));
-    if (r != l && r->stream != l->stream) {
-        HIPCHK(l, hipEventRecord(r->readers_done, l->stream));
-        r->has_readers = true;
+    // Lane j of the left handle matches its own pairs as soon as lane j of the right handle has finished them (both handles split
+    // the same n into the same lanes); with different partitions every left lane waits for all right lanes.
+    const bool aligned = l->K == r->K;
+    const size_t T = (size_t)l->g.T;
+    const int CW = JSORB_MAX_LEVELS + 1;
+    for (int j = 0; j < l->K; j++) {
+        hipStream_t st = lane_stream(l, j);
+        if (r != l) {
+            if (aligned) { if (lane_stream(r, j) != st) HIPCHK(l, hipStreamWaitEvent(st, r->lane_done[j], 0)); }
+            else
+                for (int i = 0; i < r->K; i++)
+                    if (lane_stream(r, i) != st) HIPCHK(l, hipStreamWaitEvent(st, r->lane_done[i], 0));
+        }
+        const int f = l->lane_first[j], m = l->lane_first[j + 1] - f;
+        ImageSrc srcL = l->src, srcR = r->src;
+        srcL.l0 += (size_t)f * srcL.l0_stride;
+        srcR.l0 += (size_t)f * srcR.l0_stride;
+        HIPCHK(l, hipMemsetAsync(l->st_stats + f * 8, 0, sizeof(int) * 8 * m, st));
+        TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, srcL, l->slab + (size_t)f * l->g.slab_bytes, srcR, r->slab + (size_t)f * r->g.slab_bytes,
+                                              l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
+                                              r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_len,
+                                              l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st));
+        TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
+                                              l->st_stats + f * 8, m, st));
+        HIPCHK(l, hipGetLastError());
+        HIPCHK(l, hipMemcpyAsync(l->h_stats + f * 8, l->st_stats + f * 8, sizeof(int) * 8 * m, hipMemcpyDeviceToHost, st));
+        HIPCHK(l, hipEventRecord(l->lane_done[j], st));
+        if (r != l) HIPCHK(l, hipEventRecord(r->lane_readers_done[j], st));
+        // the L1 refinement reads both level-0 planes in place: a landing buffer is free for the next upload only after this point
+        if (l->last_stage >= 0) HIPCHK(l, hipEventRecord(l->ev_consumed[l->last_stage][j], st));
+        if (r != l && r->last_stage >= 0) HIPCHK(l, hipEventRecord(r->ev_consumed[r->last_stage][j], st));
     }
-    // the L1 refinement reads both level-0 planes in place: a landing buffer is free for the next upload only after this point
-    if (l->last_stage >= 0) HIPCHK(l, hipEventRecord(l->ev_consumed[l->last_stage], l->stream));
-    if (r->last_stage >= 0) HIPCHK(l, hipEventRecord(r->ev_consumed[r->last_stage], l->stream));
+    if (r != l) {
+        r->has_readers = true;
+        r->readers_K = l->K;
+        r->readers_n = n;
+        // the right handle's extract kernels finished before the left lanes started matching (waits above), so the left lanes'
+        // events are the ones a refill of the right landing buffer has to wait for
+        if (r->last_stage >= 0) r->consumed_K[r->last_stage] = l->K;
+    }
     l->stereo_done = true;
     l->st_mirror_valid = false;
     l->stereo_pairs = n;
+    l->counts_synced = false;
     return JSORB_OK;
 }
 
@@ -827,30 +978,94 @@ int jsorb_gather_counts_async(jsorb_extractor *l, jsorb_extractor *r, int32_t *d
     if (!l || !r || !dev_dst) return JSORB_ERR_INVALID;
     if (!l->stereo_done || l->n_images != r->n_images) { l->err = "gather_counts needs a finished stereo batch"; return JSORB_ERR_STATE; }
     HIPCHK(l, hipSetDevice(l->device));
+    for (int j = 1; j < l->K; j++) HIPCHK(l, hipStreamWaitEvent(l->stream, l->lane_done[j], 0));       // all lanes' statistics
+    for (int j = 0; j < r->K; j++)
+        if (lane_stream(r, j) != l->stream) HIPCHK(l, hipStreamWaitEvent(l->stream, r->lane_done[j], 0));
     launch_gather_counts(l->counts, r->counts, l->st_stats, dev_dst, l->n_images, l->stream);
     HIPCHK(l, hipGetLastError());
-    HIPCHK(l, hipEventRecord(l->done, l->stream));
+    HIPCHK(l, hipEventRecord(l->lane_done[0], l->stream));
     return JSORB_OK;
 }
 
 int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float mbf, int th_high, int th_low, float *u_right,
                        float *depth, jsorb_stereo_stats *stats)
 {
+    if (!l || !r) return JSORB_ERR_INVALID;
+    l->counts_synced_before_stereo = l->counts_synced;
     int rc = jsorb_stereo_match_batch_async(l, r, mb, mbf, th_high, th_low);
     if (rc) return rc;
-    const int n = jsorb_n_keypoints(l, 0);
+    // the speculative copy is sized from the host-side count, which is only current if the extract was a synchronous call
+    const int n = l->counts_synced_before_stereo ? jsorb_n_keypoints(l, 0) : 0;
     if (l->n_images == 1 && n > 0) {              // results ride in the same round trip as the statistics
         HIPCHK(l, hipMemcpyAsync(l->h_u, l->st_u, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, l->stream));
         HIPCHK(l, hipMemcpyAsync(l->h_d, l->st_d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, l->stream));
     }
     rc = jsorb_sync(l);
     if (rc) return rc;
-    l->st_mirror_valid = l->n_images == 1;
+    l->st_mirror_valid = l->n_images == 1 && n > 0;
     rc = jsorb_copy_stereo(l, 0, u_right, depth, stats);
     if (rc) return rc;
     if (stats) stats->n_right = jsorb_n_keypoints(r, 0);
     return JSORB_OK;
 }
+
+// ---- memory calls behind orb_cuda::SyncedMem<T> (include/jsorb_compat.hpp) ----
+static thread_local std::string g_mem_err;
+#define MEMCHK(call)                                                              \
+    do {                                                                          \
+        hipError_t _s = (call);                                                   \
+        if (_s != hipSuccess) {                                                   \
+            g_mem_err = std::string(#call) + ": " + hipGetErrorString(_s);        \
+            return JSORB_ERR_HIP;                                                 \
+        }                                                                         \
+    } while (0)
+
+const char *jsorb_mem_last_error(void) { return g_mem_err.c_str(); }
+int jsorb_mem_set_device(int device_id) { MEMCHK(hipSetDevice(device_id)); return JSORB_OK; }
+int jsorb_mem_alloc_host(size_t bytes, void **host_pinned)
+{
+    if (!host_pinned) return JSORB_ERR_INVALID;
+    *host_pinned = nullptr;
+    if (bytes == 0) return JSORB_OK;
+    MEMCHK(hipHostMalloc(host_pinned, bytes));
+    return JSORB_OK;
+}
+int jsorb_mem_alloc_device(size_t bytes, void **device)
+{
+    if (!device) return JSORB_ERR_INVALID;
+    *device = nullptr;
+    if (bytes == 0) return JSORB_OK;
+    MEMCHK(hipMalloc(device, bytes));
+    return JSORB_OK;
+}
+int jsorb_mem_alloc_device_pitched(size_t width_bytes, size_t height, void **device, size_t *pitch)
+{
+    if (!device || !pitch) return JSORB_ERR_INVALID;
+    *device = nullptr; *pitch = 0;
+    if (width_bytes == 0 || height == 0) return JSORB_OK;
+    MEMCHK(hipMallocPitch(device, pitch, width_bytes, height));
+    return JSORB_OK;
+}
+int jsorb_mem_free_host(void *p) { if (p) MEMCHK(hipHostFree(p)); return JSORB_OK; }
+int jsorb_mem_free_device(void *p) { if (p) MEMCHK(hipFree(p)); return JSORB_OK; }
+int jsorb_mem_stream_create(void **stream)
+{
+    if (!stream) return JSORB_ERR_INVALID;
+    hipStream_t s = nullptr;
+    MEMCHK(hipStreamCreate(&s));         // blocking flag like cudaStreamCreate: ordered against the null stream
+    *stream = (void *)s;
+    return JSORB_OK;
+}
+int jsorb_mem_stream_destroy(void *stream) { if (stream) MEMCHK(hipStreamDestroy((hipStream_t)stream)); return JSORB_OK; }
+int jsorb_mem_stream_sync(void *stream) { MEMCHK(hipStreamSynchronize((hipStream_t)stream)); return JSORB_OK; }
+int jsorb_mem_h2d(void *d, const void *h, size_t n) { if (n) MEMCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return JSORB_OK; }
+int jsorb_mem_d2h(void *h, const void *d, size_t n) { if (n) MEMCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return JSORB_OK; }
+int jsorb_mem_d2d(void *d, const void *s, size_t n) { if (n) MEMCHK(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice)); return JSORB_OK; }
+int jsorb_mem_h2d_async(void *d, const void *h, size_t n, void *st) { if (n) MEMCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)st)); return JSORB_OK; }
+int jsorb_mem_d2h_async(void *h, const void *d, size_t n, void *st) { if (n) MEMCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)st)); return JSORB_OK; }
+int jsorb_mem_d2d_async(void *d, const void *s, size_t n, void *st) { if (n) MEMCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); return JSORB_OK; }
+int jsorb_mem_set_zero(void *d, size_t n) { if (n) MEMCHK(hipMemset(d, 0, n)); return JSORB_OK; }
+int jsorb_mem_set_zero_async(void *d, size_t n, void *st) { if (n) MEMCHK(hipMemsetAsync(d, 0, n, (hipStream_t)st)); return JSORB_OK; }
 
 int jsorb_enable_kernel_timing(jsorb_extractor *e, int on)
 {

@@ -30,7 +30,11 @@ EXPORTS = [
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
     "jsorb_copy_stereo", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
     "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
-    "jsorb_unpack_frame", "jsorb_assign_features_to_grid",
+    "jsorb_unpack_frame", "jsorb_assign_features_to_grid", "jsorb_copy_level_mask",
+    "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
+    "jsorb_mem_free_device", "jsorb_mem_stream_create", "jsorb_mem_stream_destroy", "jsorb_mem_stream_sync", "jsorb_mem_h2d", "jsorb_mem_d2h",
+    "jsorb_mem_d2d", "jsorb_mem_h2d_async", "jsorb_mem_d2h_async", "jsorb_mem_d2d_async", "jsorb_mem_set_zero", "jsorb_mem_set_zero_async",
+    "jsorb_mem_last_error",
 ]
 
 
@@ -92,6 +96,7 @@ def load_library(path=None):
         "jsorb_inv_scale": (F, [P, I]),
         "jsorb_level_image_device": (P, [P, I, I, I]),
         "jsorb_copy_level_image": (I, [P, I, I, I, P]),
+        "jsorb_copy_level_mask": (I, [P, I, P]),
         "jsorb_copy_tile_candidates": (I, [P, I, P, P, P]),
         "jsorb_copy_angles": (I, [P, I, P]),
         "jsorb_stereo_match": (I, [P, P, F, F, I, I, P, P, C.POINTER(JsorbStereoStats)]),
@@ -296,6 +301,13 @@ class ORBExtractor:
         h, w = self.level_dims()[level]
         out = np.zeros((h, w), np.uint8)
         self._chk(self._lib.jsorb_copy_level_image(self._h, image, level, int(blurred), out.ctypes.data))
+        return out
+
+    def level_mask(self, level):
+        """ORB_GPU::masks_[level] (orb_gpu.cpp:64-91): 0 / 255 plane of the level"""
+        h, w = self.level_dims()[level]
+        out = np.zeros((h, w), np.uint8)
+        self._chk(self._lib.jsorb_copy_level_mask(self._h, level, out.ctypes.data))
         return out
 
     def tile_candidates(self, image=0):

@@ -65,6 +65,8 @@ def _load(native=False):
         "orc_nms_ms_gpu_candidates": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "orc_orientation_px": (C.c_float, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
         "orc_descriptor_px": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+        "orc_pack_level": (None, [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+        "orc_l1_sums": (None, [C.c_int] + [C.c_void_p] * 8),
         "orc_project_points": (None, [C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 8 + [C.c_void_p] * 4),
         "orc_hamming_pairs": (None, [C.c_int] + [C.c_void_p] * 5),
         "orc_logf": (C.c_float, [C.c_float]),
@@ -81,7 +83,7 @@ def _load(native=False):
                        ("orc_n_tile_h", C.c_int), ("orc_n_tile_w", C.c_int), ("orc_level_offset", C.c_int),
                        ("orc_level_n_keypoints", C.c_int),
                        ("orc_level_image", C.POINTER(C.c_uint8)), ("orc_level_blurred", C.POINTER(C.c_uint8)),
-                       ("orc_level_score", C.POINTER(C.c_int32)), ("orc_kp_x", C.POINTER(C.c_int32)),
+                       ("orc_level_score", C.POINTER(C.c_int32)), ("orc_level_mask", C.POINTER(C.c_uint8)), ("orc_kp_x", C.POINTER(C.c_int32)),
                        ("orc_kp_y", C.POINTER(C.c_int32)), ("orc_kp_score", C.POINTER(C.c_int32)),
                        ("orc_kp_angle", C.POINTER(C.c_float))]:
         sig[lvl_fn] = (rt, [P, C.c_int])
@@ -188,6 +190,10 @@ class OracleExtractor:
         h, w = self.level_dims()[i]
         return _arr(self.l.orc_level_score(self.h, i), h * w, np.int32).reshape(h, w)
 
+    def level_mask(self, i):
+        h, w = self.level_dims()[i]
+        return _arr(self.l.orc_level_mask(self.h, i), h * w, np.uint8).reshape(h, w)
+
     def tiles(self):
         return (_arr(self.l.orc_tile_x(self.h), self.T, np.int32), _arr(self.l.orc_tile_y(self.h), self.T, np.int32),
                 _arr(self.l.orc_tile_score(self.h), self.T, np.int32))
@@ -210,6 +216,35 @@ def stereo_match(left, right, mb, mbf, th_high=100, th_low=50):
     stats["best_right"] = _arr(left.l.orc_stereo_best_right(left.h), n, np.int32)
     stats["best_dist"] = _arr(left.l.orc_stereo_best_dist(left.h), n, np.int32)
     return u[:n], d[:n], stats
+
+
+def pack_level(x, y, score, angle, octave, scale, n_total=None, kp_offset=0, out=None, native=False):
+    """K11 for one level (orc_pack_level): returns / fills the 6 x n_total int32 SoA."""
+    x, y, score = (np.ascontiguousarray(a, np.int32) for a in (x, y, score))
+    angle = np.ascontiguousarray(angle, np.float32)
+    n = len(x)
+    n_total = n if n_total is None else n_total
+    if out is None:
+        out = np.zeros(6 * n_total, np.int32)
+    lib(native).orc_pack_level(n, octave, float(scale), x.ctypes.data, y.ctypes.data, score.ctypes.data, angle.ctypes.data, n_total, kp_offset,
+                               out.ctypes.data)
+    return out
+
+
+def l1_sums(levels_left, levels_right, x_left, x_right, y, octave, native=False):
+    """K13 + cublasSgemv (orc_l1_sums): [m, 11] float32 window sums; levels_* are lists of contiguous uint8 planes (pitch = width)."""
+    levels_left = [np.ascontiguousarray(a, np.uint8) for a in levels_left]
+    levels_right = [np.ascontiguousarray(a, np.uint8) for a in levels_right]
+    x_left, x_right, y, octave = (np.ascontiguousarray(a, np.int32) for a in (x_left, x_right, y, octave))
+    m = len(x_left)
+    out = np.zeros((m, 11), np.float32)
+    PA = C.c_void_p * len(levels_left)
+    pl, pr = PA(*[a.ctypes.data for a in levels_left]), PA(*[a.ctypes.data for a in levels_right])
+    widths = np.array([a.shape[1] for a in levels_left], np.int32)
+    if m:
+        lib(native).orc_l1_sums(m, x_left.ctypes.data, x_right.ctypes.data, y.ctypes.data, octave.ctypes.data, C.cast(pl, C.c_void_p), C.cast(pr, C.c_void_p),
+                                widths.ctypes.data, out.ctypes.data)
+    return out
 
 
 def bench_pairs(lefts, rights, mb, mbf, seconds, n_threads, native=True, **kw):

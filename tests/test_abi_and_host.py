@@ -104,3 +104,37 @@ def test_cpp_compat_shim_compiles_and_links(libpath, tmp_path):
                            os.path.join(ROOT, "examples", "stereo_frame.cpp"), "-L", os.path.dirname(libpath), "-ljsorb",
                            "-lpthread", "-Wl,-rpath," + os.path.dirname(libpath), "-o", exe])
     assert os.path.exists(exe)
+
+
+def test_cpp_syncedmem_example_compiles_and_links(libpath, tmp_path):
+    """examples/search_by_projection.cpp: the SyncedMem<T> call pattern of ORBmatcher.cpp:1673-1773 / Tracking.cpp:1427-1600 (run on the GPU box
+    by tests/test_gpu_parity.py::test_cpp_syncedmem_call_pattern_of_orbmatcher_and_tracking)"""
+    import subprocess
+    exe = str(tmp_path / "search_by_projection")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "search_by_projection.cpp"), "-L", os.path.dirname(libpath), "-ljsorb",
+                           "-Wl,-rpath," + os.path.dirname(libpath), "-o", exe])
+    assert os.path.exists(exe)
+
+
+def test_opencv_overloads_type_check_against_a_declaration_only_double():
+    """TYPE-CHECK ONLY: OpenCV is not installed here; tests/cpp/opencv_double declares the handful of cv:: types the JSORB_WITH_OPENCV
+    overloads touch, and tests/cpp/frame_compile_check.cpp is a Frame-shaped class that calls the shim with the reference's own
+    signatures - extract(const cv::Mat&, SyncedMem<int>&, SyncedMem<uchar>&), ORB_GPU::ORB_compute_stereo_match(... std::vector<cv::KeyPoint>& ...),
+    the string-mask constructor."""
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "tests", "cpp", "opencv_double"), os.path.join(ROOT, "tests", "cpp", "frame_compile_check.cpp")])
+
+
+def test_compat_header_covers_the_whole_syncedmem_surface():
+    """every member of include/cuda/synced_mem_holder.hpp:15-58 (names listed here, not read from the reference at run time)"""
+    src = open(os.path.join(ROOT, "include", "jsorb_compat.hpp")).read()
+    for member in ("void resize(int count)", "void resize_pitched(size_t width, size_t height)", "Dtype *cpu_data()", "Dtype *gpu_data()",
+                   "void to_cpu(void)", "void to_gpu(void)", "void to_cpu(int count)", "void to_gpu(int count)", "void to_cpu_async(void)",
+                   "void to_gpu_async(void)", "void to_cpu_async(cudaStream_t &cu_stream)", "void to_gpu_async(cudaStream_t &cu_stream)",
+                   "void to_cpu_async(int count)", "void to_gpu_async(int count)", "void to_cpu_async(cudaStream_t &cu_stream, int count)",
+                   "void to_gpu_async(cudaStream_t &cu_stream, int count)", "void sync_stream(void)", "void set_zero_gpu(void)",
+                   "void set_zero_gpu_async(void)", "void set_zero_cpu(void)", "int count_;", "int capacity_;", "Dtype *cpu_data_;", "Dtype *gpu_data_;",
+                   "size_t pitch_;", "cudaStream_t cu_stream_;", "cudaError_t cu_error_;"):
+        assert member in src, member

@@ -112,3 +112,28 @@ def test_pattern_tables_identical_and_hashed():
     assert (xs[0], ys[0], xs[1], ys[1], xs[2], ys[2], xs[3], ys[3]) == (8, -3, 9, 5, 4, 2, 7, -12)
     assert (xs[510], ys[510], xs[511], ys[511]) == (-1, -6, 0, -11)
     assert max(map(abs, xs + ys)) == 13
+
+
+def _opencv_resize_nn_index(dst_size, src_size):
+    """OpenCV imgproc/resize.cpp resizeNN: fx = dst/(double)src; ifx = 1./fx; sx = min(cvFloor(x*ifx), src-1)"""
+    ifx = 1.0 / (dst_size / float(src_size))
+    return np.minimum(np.floor(np.arange(dst_size) * ifx).astype(np.int64), src_size - 1)
+
+
+def test_mask_pyramid_uses_opencv_resize_nn_indices(po):
+    """orb_gpu.cpp:77-81: cv::resize(mask, ..., CV_INTER_NN) then threshold(10).  The counter-examples of the round-1 review: with
+    floor(x*src/dst) instead of floor(x*(1/(dst/src))) these positions read the neighbouring source pixel."""
+    assert _opencv_resize_nn_index(626, 752)[313] == 375 and (313 * 752) // 626 == 376
+    assert _opencv_resize_nn_index(231, 480)[77] == 159 and (77 * 480) // 231 == 160
+    assert _opencv_resize_nn_index(231, 480)[154] == 319 and (154 * 480) // 231 == 320
+    assert _opencv_resize_nn_index(154, 320)[77] == 159 and (77 * 320) // 154 == 160
+    n_diff_720_200 = int((_opencv_resize_nn_index(200, 720) != (np.arange(200) * 720) // 200).sum())
+    assert n_diff_720_200 == 29
+    for H, W, L in ((480, 752, 8), (240, 320, 3), (720, 1280, 8)):
+        rng = np.random.default_rng(H)
+        mask = rng.integers(0, 2, (H, W), dtype=np.uint8) * 200 + rng.integers(0, 11, (H, W), dtype=np.uint8)      # 0..10 -> masked, 200..210 -> kept
+        o = po.OracleExtractor(height=H, width=W, n_levels=L, tile_h=30, tile_w=30, mask=mask)
+        for lv, (h, w) in enumerate(o.level_dims()):
+            sy, sx = _opencv_resize_nn_index(h, H), _opencv_resize_nn_index(w, W)
+            want = np.where(mask[sy][:, sx] > 10, 255, 0).astype(np.uint8)
+            assert np.array_equal(o.level_mask(lv), want), (H, W, lv)
