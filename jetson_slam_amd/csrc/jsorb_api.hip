@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -20,7 +21,7 @@
 #include "../../include/jsorb.h"
 #include "jsorb_launch.h"
 
-#define JSORB_MAX_LANES 4
+#define JSORB_MAX_LANES 8
 
 using namespace jsorb;
 
@@ -43,15 +44,20 @@ struct jsorb_extractor {
     // (lane 0 = `stream`, the handle's main / caller-provided stream).  The sparse, latency-bound stages of one lane (FAST ring
     // test / NMS, descriptor gathers, the single-workgroup compaction and median kernels) then overlap the streaming stages of
     // another one.  A single frame (the reference's call shape) uses lane 0 only.
-    hipStream_t lane_own[JSORB_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t lane_done[JSORB_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};          // after the last work enqueued on lane j
-    hipEvent_t lane_readers_done[JSORB_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};  // recorded on ANOTHER handle's lanes after they read this handle's buffers
+    hipStream_t lane_used[JSORB_MAX_LANES] = {};   // the stream lane j of the LAST batch ran on (main stream for a one-lane batch, the device's lane pool otherwise)
+    hipStream_t readers_stream[JSORB_MAX_LANES] = {};
+    hipEvent_t lane_done[JSORB_MAX_LANES] = {};          // after the last work enqueued on lane j
+    hipEvent_t lane_readers_done[JSORB_MAX_LANES] = {};  // recorded on ANOTHER handle's lanes after they read this handle's buffers
     hipEvent_t ev_fork = nullptr;
-    int max_lanes = JSORB_MAX_LANES;
+    int max_lanes = 4;
+    int stagger = 0;                   // software pipeline across lanes (JSORB_LANE_STAGGER=1; measured slower: 77.8 k vs 80 k pairs/s)
+    hipEvent_t ev_stage[JSORB_MAX_LANES][6] = {};
+    double lane_min_px = 7.0e6;
     int K = 1;                 // lanes used by the last batch
-    int lane_first[JSORB_MAX_LANES + 1] = {0, 0, 0, 0, 0};
+    int lane_first[JSORB_MAX_LANES + 1] = {};
     bool has_readers = false;
     int readers_K = 0, readers_n = 0;
+    bool main_stream_dirty = false;    // this call enqueued input copies on the main stream: the lanes must fork after them
     bool counts_synced = false;        // h_counts / h_stats reflect the last enqueued batch (set by jsorb_sync)
     bool counts_synced_before_stereo = false;
     size_t detect_lds = 0, pyr_lds = 0;
@@ -62,7 +68,7 @@ struct jsorb_extractor {
     uint8_t *stage[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr};
-    hipEvent_t ev_consumed[2][JSORB_MAX_LANES] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // per landing buffer and lane
+    hipEvent_t ev_consumed[2][JSORB_MAX_LANES] = {};   // per landing buffer and lane
     int consumed_K[2] = {0, 0};        // lanes whose ev_consumed must be waited for before the buffer is refilled (0: never used)
     int stage_cur = 0, last_stage = -1;
     uint32_t *lut_bits = nullptr;
@@ -303,19 +309,43 @@ int drain_timed(jsorb_extractor *e)
         if (_rc) return _rc;                                 \
     } while (0)
 
-inline hipStream_t lane_stream(const jsorb_extractor *e, int j) { return j == 0 ? e->stream : e->lane_own[j]; }
+// Lane streams are a per-device POOL shared by every handle of the process: lane j of the left extractor, lane j of the right
+// extractor and lane j of their stereo match land on the SAME stream, in call order - a chain of 12 kernels per lane with no
+// cross-stream dependency inside it, and the chains of different lanes drift out of phase so that different stages overlap on the
+// GPU.  (Private lane streams per handle put all lanes in lock-step on the same stage and tie left and right together with
+// events: measured 80 k pairs/s against 85 k for the pooled form at C2.)
+struct LanePool {
+    std::mutex m;
+    hipStream_t s[JSORB_MAX_LANES] = {};
+};
+LanePool g_pool[16];
+
+int pool_stream(jsorb_extractor *e, int j, hipStream_t *out)
+{
+    LanePool &p = g_pool[e->device & 15];
+    std::lock_guard<std::mutex> lk(p.m);
+    if (!p.s[j]) HIPCHK(e, hipStreamCreateWithFlags(&p.s[j], hipStreamNonBlocking));
+    *out = p.s[j];
+    return JSORB_OK;
+}
+
+inline hipStream_t lane_stream(const jsorb_extractor *e, int j) { return e->lane_used[j]; }      // of the LAST batch
 
 // Split n images into contiguous lanes.  A lane keeps at least ~7 Mpx of level-0 pixels (about 20 images of 752x480) so that each
 // launch still fills the 256 CUs; per-kernel timing (which serialises launches anyway) and small batches use one lane.
 int plan_lanes(const jsorb_extractor *e, int n, int *first)
 {
     const double px = (double)e->g.lv[0].H * e->g.lv[0].W;
-    const int min_per_lane = std::max(1, (int)std::ceil(7.0e6 / px));
+    const int min_per_lane = std::max(1, (int)std::ceil(e->lane_min_px / px));
     int K = std::min(e->max_lanes, n / min_per_lane);
     if (K < 1 || e->timing) K = 1;
-    const int base = n / K, rem = n % K;
+    // lane sizes in units of 8 images where possible: the XCD-aware workgroup mapping (xcd_map) pads a launch to a multiple of 8 images,
+    // and 43 + 43 + 42 images cost 10 % more workgroup slots than 48 + 40 + 40 (measured: 3 uneven lanes 77.8 k, 4 even lanes 84.8 k pairs/s)
+    const int unit = n >= 8 * K ? 8 : 1;
+    const int units = n / unit, base = units / K, rem = units % K;
     first[0] = 0;
-    for (int j = 0; j < K; j++) first[j + 1] = first[j] + base + (j < rem ? 1 : 0);
+    for (int j = 0; j < K; j++) first[j + 1] = first[j] + unit * (base + (j < rem ? 1 : 0));
+    first[K] = n;                                   // the last lane takes the remainder (< 8 images)
     return K;
 }
 
@@ -324,28 +354,31 @@ int plan_lanes(const jsorb_extractor *e, int n, int *first)
 //  * the previous batch of this handle, when its lane partition differs (same partition: same-stream order is enough)
 //  * a stereo match enqueued on ANOTHER handle's lanes that may still read this handle's previous results
 //  * `input_ready` (optional): e.g. the upload of this batch on the copy stream
-int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, hipEvent_t input_ready)
+int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, const hipStream_t *ls, hipEvent_t input_ready)
 {
-    if (K > 1) {
+    if ((K > 1 || ls[0] != e->stream) && (e->stream != e->own_stream || e->main_stream_dirty)) {
+        // a caller-provided main stream (or copies this call put on the main stream) may carry work the images depend on.  The
+        // handle's OWN stream only ever carries this handle's work, which the lanes order themselves against below.
         HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
-        for (int j = 1; j < K; j++) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->ev_fork, 0));
+        for (int j = 0; j < K; j++)
+            if (ls[j] != e->stream) HIPCHK(e, hipStreamWaitEvent(ls[j], e->ev_fork, 0));
     }
-    const bool same = e->extracted && K == e->K && n == e->n_images;
-    if (e->extracted && !same)
+    e->main_stream_dirty = false;
+    if (e->extracted) {         // the previous batch of this handle: wherever a lane now runs on another stream than the lane that last touched its images
+        const bool same_split = K == e->K && n == e->n_images;
         for (int j = 0; j < K; j++)
             for (int i = 0; i < e->K; i++)
-                if (i != j) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->lane_done[i], 0));
-    if (e->has_readers) {
+                if ((same_split ? i == j : true) && e->lane_used[i] != ls[j]) HIPCHK(e, hipStreamWaitEvent(ls[j], e->lane_done[i], 0));
+    }
+    if (e->has_readers) {       // a stereo match enqueued through ANOTHER handle may still read this handle's previous results
         const bool aligned = e->readers_K == K && e->readers_n == n;
-        for (int j = 0; j < K; j++) {
-            if (aligned) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->lane_readers_done[j], 0));
-            else
-                for (int i = 0; i < e->readers_K; i++) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), e->lane_readers_done[i], 0));
-        }
+        for (int j = 0; j < K; j++)
+            for (int i = 0; i < e->readers_K; i++)
+                if ((aligned ? i == j : true) && e->readers_stream[i] != ls[j]) HIPCHK(e, hipStreamWaitEvent(ls[j], e->lane_readers_done[i], 0));
         e->has_readers = false;
     }
     if (input_ready)
-        for (int j = 0; j < K; j++) HIPCHK(e, hipStreamWaitEvent(lane_stream(e, j), input_ready, 0));
+        for (int j = 0; j < K; j++) HIPCHK(e, hipStreamWaitEvent(ls[j], input_ready, 0));
     return JSORB_OK;
 }
 
@@ -354,32 +387,55 @@ int run_pipeline(jsorb_extractor *e, int n, hipEvent_t input_ready = nullptr)
     const Geometry &g = e->g;
     int first[JSORB_MAX_LANES + 1];
     const int K = plan_lanes(e, n, first);
-    int rc = order_lanes_for_new_batch(e, K, n, input_ready);
-    if (rc) return rc;
+    hipStream_t ls[JSORB_MAX_LANES];
+    int rc;
+    if (K == 1) ls[0] = e->stream;                  // one lane (single frame, small batch, per-kernel timing): the handle's main stream
+    else
+        for (int j = 0; j < K; j++) {
+            if ((rc = pool_stream(e, j, &ls[j]))) return rc;
+            if (e->stagger && j + 1 < K && !e->ev_stage[j][0])
+                for (int q = 0; q < 6; q++) HIPCHK(e, hipEventCreateWithFlags(&e->ev_stage[j][q], hipEventDisableTiming));
+        }
+    if ((rc = order_lanes_for_new_batch(e, K, n, ls, input_ready))) return rc;
     const size_t T = (size_t)g.T;
     const int CW = JSORB_MAX_LEVELS + 1;
     for (int j = 0; j < K; j++) {
         const int f = first[j], m = first[j + 1] - f;
-        hipStream_t st = lane_stream(e, j);
+        hipStream_t st = ls[j];
         ImageSrc src = e->src;
         src.l0 += (size_t)f * src.l0_stride;
         uint8_t *slab = e->slab + (size_t)f * g.slab_bytes, *blur = e->blur + (size_t)f * g.slab_bytes;
         unsigned long long *tile_out = e->tile_out + f * T, *kp = e->kp + f * T;
         int *counts = e->counts + f * CW;
-        TIMED(e, JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
-        TIMED(e, JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
+        // Software pipeline across the lanes: stage s of lane j starts when stage s of lane j-1 has finished, so that at any time
+        // DIFFERENT stages are resident on the GPU (k_detect's sparse ring-test phases next to k_blur's FMA chains next to
+        // k_describe's gathers) instead of the same stage of all lanes competing for the same unit.
+        int stage = 0;
+#define JSORB_STAGE(id, launch_stmt)                                                                                        \
+        do {                                                                                                                \
+            if (e->stagger && j > 0) HIPCHK(e, hipStreamWaitEvent(st, e->ev_stage[j - 1][stage], 0));                       \
+            TIMED(e, id, launch_stmt);                                                                                      \
+            if (e->stagger && j + 1 < K) HIPCHK(e, hipEventRecord(e->ev_stage[j][stage], st));                              \
+            stage++;                                                                                                        \
+        } while (0)
+        JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
+        JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
         if (e->nms_ms)
-            TIMED(e, JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
-                                                   e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
-        TIMED(e, JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st));
-        TIMED(e, JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
-        TIMED(e, JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st));
+            JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
+                                                      e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
+        JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st));
+        JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
+        JSORB_STAGE(JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st));
+#undef JSORB_STAGE
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipMemcpyAsync(e->h_counts + f * CW, counts, sizeof(int) * CW * m, hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
     }
     e->K = K;
     for (int j = 0; j <= K; j++) e->lane_first[j] = first[j];
+    for (int j = 0; j < K; j++) e->lane_used[j] = ls[j];
+    if (K > 1 && e->stream != e->own_stream)        // a caller-provided main stream observes the batch: whatever the caller enqueues on it next runs after the lanes
+        for (int j = 0; j < K; j++) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_done[j], 0));
     e->n_images = n;
     e->extracted = true;
     e->stereo_done = false;
@@ -419,12 +475,13 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    for (int j = 0; j < JSORB_MAX_LANES; j++) {
-        if (j > 0) HIPCHK(e, hipStreamCreateWithFlags(&e->lane_own[j], hipStreamNonBlocking));
+    for (int j = 0; j < JSORB_MAX_LANES; j++) {      // the extra lane STREAMS are created on first use (run_pipeline): a single-frame handle never needs them
         HIPCHK(e, hipEventCreateWithFlags(&e->lane_done[j], hipEventDisableTiming));
         HIPCHK(e, hipEventCreateWithFlags(&e->lane_readers_done[j], hipEventDisableTiming));
     }
-    if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));
+    if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));      // tuning hooks
+    if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
+    if (const char *mp = getenv("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
     for (int i = 0; i < g.L; i++) {                        // needed by the LDS layout: the arg-max form needs 256 B where the literal tree needs 1 KB
         uint8_t tr[256];
         g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !getenv("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
@@ -542,8 +599,8 @@ void jsorb_destroy(jsorb_extractor *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    for (int j = 1; j < JSORB_MAX_LANES; j++)
-        if (e->lane_own[j]) (void)hipStreamSynchronize(e->lane_own[j]);
+    for (int j = 0; j < e->K; j++)
+        if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
                     e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
@@ -557,7 +614,8 @@ void jsorb_destroy(jsorb_extractor *e)
     for (int j = 0; j < JSORB_MAX_LANES; j++) {
         if (e->lane_done[j]) (void)hipEventDestroy(e->lane_done[j]);
         if (e->lane_readers_done[j]) (void)hipEventDestroy(e->lane_readers_done[j]);
-        if (e->lane_own[j]) (void)hipStreamDestroy(e->lane_own[j]);
+        for (int q = 0; q < 6; q++)
+            if (e->ev_stage[j][q]) (void)hipEventDestroy(e->ev_stage[j][q]);
     }
     for (int k = 0; k < 2; k++) {
         if (e->ev_copied[k]) (void)hipEventDestroy(e->ev_copied[k]);
@@ -595,7 +653,9 @@ int jsorb_sync(jsorb_extractor *e)
 {
     if (!e) return JSORB_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
-    for (int j = 0; j < e->K; j++) HIPCHK(e, hipStreamSynchronize(lane_stream(e, j)));
+    if (e->extracted)
+        for (int j = 0; j < e->K; j++) HIPCHK(e, hipStreamSynchronize(lane_stream(e, j)));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     e->counts_synced = true;
     return drain_timed(e);
 }
@@ -605,9 +665,11 @@ int jsorb_sync(jsorb_extractor *e)
 static int join_previous_on_main(jsorb_extractor *e)
 {
     if (e->extracted)
-        for (int i = 1; i < e->K; i++) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_done[i], 0));
+        for (int i = 0; i < e->K; i++)
+            if (e->lane_used[i] != e->stream) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_done[i], 0));
     if (e->has_readers)
-        for (int i = 0; i < e->readers_K; i++) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_readers_done[i], 0));
+        for (int i = 0; i < e->readers_K; i++)
+            if (e->readers_stream[i] != e->stream) HIPCHK(e, hipStreamWaitEvent(e->stream, e->lane_readers_done[i], 0));
     return JSORB_OK;
 }
 
@@ -657,6 +719,7 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
         return mark_buffer_consumed(e, k);
     }
     if ((rc = join_previous_on_main(e))) return rc;
+    e->main_stream_dirty = true;
     for (int i = 0; i < n_images; i++)   // strided input: one 2-D copy per image into the pitched slab (main stream; the lanes fork after it)
         HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
                                    l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
@@ -677,6 +740,7 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     } else {
         const int rc = join_previous_on_main(e);
         if (rc) return rc;
+        e->main_stream_dirty = true;
         for (int i = 0; i < n_images; i++)
             HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, dev_images + (size_t)i * image_stride, step,
                                        l0.W, l0.H, hipMemcpyDeviceToDevice, e->stream));
@@ -921,7 +985,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
         HIPCHK(l, hipGetLastError());
         HIPCHK(l, hipMemcpyAsync(l->h_stats + f * 8, l->st_stats + f * 8, sizeof(int) * 8 * m, hipMemcpyDeviceToHost, st));
         HIPCHK(l, hipEventRecord(l->lane_done[j], st));
-        if (r != l) HIPCHK(l, hipEventRecord(r->lane_readers_done[j], st));
+        if (r != l) { HIPCHK(l, hipEventRecord(r->lane_readers_done[j], st)); r->readers_stream[j] = st; }
         // the L1 refinement reads both level-0 planes in place: a landing buffer is free for the next upload only after this point
         if (l->last_stage >= 0) HIPCHK(l, hipEventRecord(l->ev_consumed[l->last_stage][j], st));
         if (r != l && r->last_stage >= 0) HIPCHK(l, hipEventRecord(r->ev_consumed[r->last_stage][j], st));
@@ -978,12 +1042,18 @@ int jsorb_gather_counts_async(jsorb_extractor *l, jsorb_extractor *r, int32_t *d
     if (!l || !r || !dev_dst) return JSORB_ERR_INVALID;
     if (!l->stereo_done || l->n_images != r->n_images) { l->err = "gather_counts needs a finished stereo batch"; return JSORB_ERR_STATE; }
     HIPCHK(l, hipSetDevice(l->device));
-    for (int j = 1; j < l->K; j++) HIPCHK(l, hipStreamWaitEvent(l->stream, l->lane_done[j], 0));       // all lanes' statistics
+    for (int j = 0; j < l->K; j++)                                                                         // all lanes' statistics
+        if (lane_stream(l, j) != l->stream) HIPCHK(l, hipStreamWaitEvent(l->stream, l->lane_done[j], 0));
     for (int j = 0; j < r->K; j++)
         if (lane_stream(r, j) != l->stream) HIPCHK(l, hipStreamWaitEvent(l->stream, r->lane_done[j], 0));
     launch_gather_counts(l->counts, r->counts, l->st_stats, dev_dst, l->n_images, l->stream);
     HIPCHK(l, hipGetLastError());
-    HIPCHK(l, hipEventRecord(l->lane_done[0], l->stream));
+    HIPCHK(l, hipEventRecord(l->lane_done[0], l->stream));      // "everything of this handle so far" now includes the gather (it waited for every lane)
+    // the next batch of either handle rewrites the count tables the gather kernel reads: their lanes continue after it
+    HIPCHK(l, hipEventRecord(l->ev_fork, l->stream));
+    for (jsorb_extractor *h : {l, r})
+        for (int j = 0; j < h->K; j++)
+            if (lane_stream(h, j) != l->stream) HIPCHK(l, hipStreamWaitEvent(lane_stream(h, j), l->ev_fork, 0));
     return JSORB_OK;
 }
 

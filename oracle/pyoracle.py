@@ -75,6 +75,7 @@ def _load(native=False):
         "orc_is_in_frustum": (None, [C.c_int] + [C.c_void_p] * 12 + [C.c_float] * 4 + [C.c_int] * 5 + [C.c_float] * 2 + [C.c_void_p] * 6),
         "orc_bench_pairs": (C.c_long, [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double,
                                       C.c_int, C.POINTER(C.c_double)]),
+        "orc_pairs_digest": (C.c_int, [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
         "orc_stereo_match": (C.c_int, [P, P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.POINTER(OrcStereoStats)]),
     }
@@ -256,6 +257,31 @@ def bench_pairs(lefts, rights, mb, mbf, seconds, n_threads, native=True, **kw):
     el = C.c_double()
     n = l.orc_bench_pairs(C.byref(p), lefts.ctypes.data, rights.ctypes.data, lefts.shape[0], mb, mbf, seconds, n_threads, C.byref(el))
     return n, el.value
+
+
+_DIGEST_M = np.uint64(0x9E3779B97F4A7C15)
+
+
+def digest_arrays(arrays):
+    """the checksum of orc_pairs_digest over the concatenated bytes of `arrays` (numpy, wrapping uint64 arithmetic)"""
+    b = np.concatenate([np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in arrays]) if arrays else np.zeros(0, np.uint8)
+    with np.errstate(over="ignore"):
+        w = (np.arange(1, b.size + 1, dtype=np.uint64)) * _DIGEST_M
+        return int(((b.astype(np.uint64) + np.uint64(1)) * w).sum(dtype=np.uint64))
+
+
+def pairs_digest(lefts, rights, mb, mbf, n_threads, native=False, **kw):
+    """(digest[n] uint64, counts[n, 3] int32) of extract(L) + extract(R) + stereo for every pair, OpenMP over pairs"""
+    l = lib(native)
+    p = make_params(**kw)
+    lefts = np.ascontiguousarray(lefts, np.uint8)
+    rights = np.ascontiguousarray(rights, np.uint8)
+    n = lefts.shape[0]
+    dg = np.zeros(n, np.uint64)
+    cnt = np.zeros((n, 3), np.int32)
+    rc = l.orc_pairs_digest(C.byref(p), lefts.ctypes.data, rights.ctypes.data, n, mb, mbf, n_threads, dg.ctypes.data, cnt.ctypes.data)
+    assert rc == 0
+    return dg, cnt
 
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

@@ -48,6 +48,10 @@ int main(int argc, char **argv)
         const double t4 = now_us();
         if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; }
     }
+    if (getenv("JSORB_JSON"))
+        printf("{\"frames\": %d, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f}\n", frames,
+               t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames);
+    else
     printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f\n",
            t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames);
     return 0;
