@@ -126,10 +126,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-streamed / frame-latency / C4 side measurements")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: one lane, all handles on ONE HIP stream (clean per-kernel durations under rocprofv3)")
     ap.add_argument("--groups", type=int, default=1, help="split the step's pairs over this many independent left/right handle pairs on their own "
                     "HIP streams (round-1 schedule; the library now does the equivalent split internally, so the default is ONE handle pair)")
     args = ap.parse_args()
 
+    if args.single_stream:
+        os.environ["JSORB_MAX_LANES"] = "1"
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         self_launch(args)
@@ -193,7 +196,12 @@ def main():
     handles = [h for pair in groups for h in pair]
     torch_stream = torch.cuda.current_stream(dev)
     group_streams = []
-    if G > 1:                                     # round-1 schedule: one HIP stream per handle pair
+    if args.single_stream:
+        one = torch.cuda.Stream(dev)
+        group_streams.append(one)
+        for h in handles:
+            h.set_stream(one.cuda_stream)
+    elif G > 1:                                   # round-1 schedule: one HIP stream per handle pair
         for a, b in groups:
             st = torch.cuda.Stream(dev)
             group_streams.append(st)
@@ -259,7 +267,7 @@ def main():
         step()
     blocks = [timed_block(args.steps)]
     # every rank must run the same number of blocks: rank 0 decides from its first block
-    n_blocks = int(min(200, max(3, np.ceil(args.min_time / max(blocks[0], 1e-6)))))
+    n_blocks = int(min(200, max(3 if args.min_time > 0 else 1, np.ceil(args.min_time / max(blocks[0], 1e-6)))))
     if world > 1:
         nb = torch.tensor([n_blocks], dtype=torch.int64, device="cpu" if gloo else dev)
         dist.broadcast(nb, 0)

@@ -73,6 +73,10 @@ const char *jsorb_version(void);
 /* ---- extraction ---- */
 /* Reference-shaped call: one host image (step = bytes per row), results stay on the device; *n_keypoints = N.  Synchronous. */
 int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints);
+/* Same, and the results are ALSO delivered into caller-owned device buffers (6*T int32 and 32*T bytes, T = jsorb_total_tiles, the
+ * keypoint cap) in the same stream round trip: what the reference's extract() does with the caller's SyncedMem (orb_gpu.cpp:779-831
+ * writes into out_keypoints.gpu_data() / out_keypoints_desc.gpu_data()).  Either destination may be NULL. */
+int jsorb_extract_into(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints, int32_t *dev_keypoints_dst, uint8_t *dev_descriptors_dst);
 /* Same with the image already in device memory. */
 int jsorb_extract_device(jsorb_extractor *e, const uint8_t *dev_image, int step, int *n_keypoints);
 /* Batch mode: n_images (<= max_batch) images at dev_images + i*image_stride, rows `step` bytes apart.  Enqueues only; the

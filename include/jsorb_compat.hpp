@@ -275,19 +275,19 @@ public:
     // device side by a device-to-device copy on the handle's stream, the host side from the handle's pinned mirror.
     void extract(const unsigned char *image, int step, SyncedMem<int> &out_keypoints, SyncedMem<unsigned char> &out_keypoints_desc)
     {
+        // the caller's SyncedMems are sized once for the keypoint cap T (resize grows only), so that the handle can deliver the device
+        // copies in the same stream round trip as the counts; count_ is then set to the frame's 6N / 32N
+        const int T = jsorb_total_tiles(handle_);
+        if (out_keypoints.capacity_ < 6 * T) out_keypoints.resize(6 * T);
+        if (out_keypoints_desc.capacity_ < 32 * T) out_keypoints_desc.resize(32 * T);
         int n = 0;
-        if (jsorb_extract(handle_, image, step, &n) != JSORB_OK) throw std::runtime_error(std::string("jsorb_extract: ") + jsorb_last_error(handle_));
+        if (jsorb_extract_into(handle_, image, step, &n, out_keypoints.gpu_data_, out_keypoints_desc.gpu_data_) != JSORB_OK)
+            throw std::runtime_error(std::string("jsorb_extract: ") + jsorb_last_error(handle_));
         out_keypoints.resize(6 * n);
         out_keypoints_desc.resize(32 * n);
-        if (n > 0) {
-            void *st = jsorb_get_stream(handle_);
-            int rc = jsorb_mem_d2d_async(out_keypoints.gpu_data_, jsorb_keypoints_device(handle_, 0), (size_t)6 * n * sizeof(int), st);
-            if (rc == JSORB_OK) rc = jsorb_mem_d2d_async(out_keypoints_desc.gpu_data_, jsorb_descriptors_device(handle_, 0), (size_t)32 * n, st);
-            if (rc == JSORB_OK) rc = jsorb_copy_keypoints(handle_, 0, out_keypoints.cpu_data_);
-            if (rc == JSORB_OK) rc = jsorb_copy_descriptors(handle_, 0, out_keypoints_desc.cpu_data_);
-            if (rc == JSORB_OK) rc = jsorb_mem_stream_sync(st);
-            if (rc != JSORB_OK) throw std::runtime_error("jsorb: delivering the extract results failed");
-        }
+        if (n > 0 && (jsorb_copy_keypoints(handle_, 0, out_keypoints.cpu_data_) != JSORB_OK ||             // host side: from the handle's pinned mirror
+                      jsorb_copy_descriptors(handle_, 0, out_keypoints_desc.cpu_data_) != JSORB_OK))
+            throw std::runtime_error("jsorb: delivering the extract results failed");
         out_keypoints.host_fresh_ = out_keypoints_desc.host_fresh_ = true;
     }
 #ifdef JSORB_WITH_OPENCV

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,7 @@ struct jsorb_extractor {
     hipEvent_t lane_readers_done[JSORB_MAX_LANES] = {};  // recorded on ANOTHER handle's lanes after they read this handle's buffers
     hipEvent_t ev_fork = nullptr;
     int max_lanes = 4;
+    int spin_wait = 1;                 // poll instead of block when waiting for a single frame (JSORB_SPIN_WAIT=0 disables)
     int stagger = 0;                   // software pipeline across lanes (JSORB_LANE_STAGGER=1; measured slower: 77.8 k vs 80 k pairs/s)
     hipEvent_t ev_stage[JSORB_MAX_LANES][6] = {};
     double lane_min_px = 7.0e6;
@@ -59,7 +61,6 @@ struct jsorb_extractor {
     int readers_K = 0, readers_n = 0;
     bool main_stream_dirty = false;    // this call enqueued input copies on the main stream: the lanes must fork after them
     bool counts_synced = false;        // h_counts / h_stats reflect the last enqueued batch (set by jsorb_sync)
-    bool counts_synced_before_stereo = false;
     size_t detect_lds = 0, pyr_lds = 0;
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
@@ -88,13 +89,21 @@ struct jsorb_extractor {
     int *ms_grid = nullptr, *ms_scratch = nullptr;   // NMS-MS: level-0 accumulator plane (GPU mode) / mutable scores (CPU mode)
     // pinned host mirrors
     int *h_counts = nullptr, *h_stats = nullptr;
-    // single-frame synchronous calls (the reference's call shape): results are mirrored into pinned memory speculatively, in the
-    // same stream round trip as the counts, so that SyncedMem::to_cpu() / the stereo outputs cost a memcpy instead of a blocking D2H
+    // single-image calls (the reference's call shape): the kernels write their results into these pinned mirrors themselves (struct
+    // Deliver), so that SyncedMem::to_cpu() / the stereo outputs cost a memcpy instead of a blocking D2H
     int32_t *h_kp = nullptr;
     uint8_t *h_desc = nullptr;
     float *h_u = nullptr, *h_d = nullptr;
-    int spec_cap = 0;          // keypoints covered by the speculative copy (tracks the previous frame's count)
     bool mirror_valid = false, st_mirror_valid = false;
+    bool mirror_pending = false, st_mirror_pending = false;   // a single-image call is in flight whose kernels write the pinned mirrors themselves (struct Deliver)
+    // the 5-kernel chain of a single image as a HIP graph (captured on first use, replayed while the arguments stay the same): one
+    // hipGraphLaunch instead of five kernel launches on the host's critical path (JSORB_FRAME_GRAPH=0 disables)
+    hipGraphExec_t frame_graph = nullptr;
+    const void *fg_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // l0 source, its pitch, main stream, the two caller-owned destinations
+    int fg_recaptures = 0;             // consecutive frames whose arguments differed from the captured ones
+    int use_frame_graph = 1;
+    int32_t *deliver_kp_dev = nullptr;      // jsorb_extract_into: caller-owned device destinations of the next single-image pipeline
+    uint8_t *deliver_desc_dev = nullptr;
     ImageSrc src{};            // where level 0 of the last extract lives
     bool extracted = false, stereo_done = false;
     int stereo_pairs = 0;
@@ -103,6 +112,10 @@ struct jsorb_extractor {
     double k_ms[JSORB_K_COUNT] = {0};
     long k_n[JSORB_K_COUNT] = {0};
     std::string err;
+    // JSORB_TRACE_HOST=1: host-side time of the single-frame calls (H2D enqueue, kernel enqueue, wait), printed at destroy
+    bool trace_host = false;
+    double th_h2d = 0, th_enq = 0, th_wait = 0, th_st_enq = 0, th_st_wait = 0;
+    long th_n = 0, th_st_n = 0;
 };
 
 namespace {
@@ -399,6 +412,9 @@ int run_pipeline(jsorb_extractor *e, int n, hipEvent_t input_ready = nullptr)
     if ((rc = order_lanes_for_new_batch(e, K, n, ls, input_ready))) return rc;
     const size_t T = (size_t)g.T;
     const int CW = JSORB_MAX_LEVELS + 1;
+    // a single image: k_compact / k_describe write counts, keypoints and descriptors straight into the pinned host mirrors (and into
+    // the caller's device buffers, jsorb_extract_into) - no copies behind the kernels
+    const bool direct = n == 1;
     for (int j = 0; j < K; j++) {
         const int f = first[j], m = first[j + 1] - f;
         hipStream_t st = ls[j];
@@ -407,6 +423,22 @@ int run_pipeline(jsorb_extractor *e, int n, hipEvent_t input_ready = nullptr)
         uint8_t *slab = e->slab + (size_t)f * g.slab_bytes, *blur = e->blur + (size_t)f * g.slab_bytes;
         unsigned long long *tile_out = e->tile_out + f * T, *kp = e->kp + f * T;
         int *counts = e->counts + f * CW;
+        // single image on an untimed handle: replay the captured graph of the five launches when nothing they depend on has changed
+        bool capturing = false;
+        if (direct && e->use_frame_graph && !e->timing && !e->nms_ms) {
+            const void *key[5] = {e->src.l0, (const void *)(uintptr_t)e->src.l0_pitch, st, e->deliver_kp_dev, e->deliver_desc_dev};
+            if (e->frame_graph && memcmp(key, e->fg_key, sizeof key) == 0) {
+                e->fg_recaptures = 0;
+                HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
+                HIPCHK(e, hipEventRecord(e->lane_done[j], st));
+                continue;
+            }
+            if (e->frame_graph) { (void)hipGraphExecDestroy(e->frame_graph); e->frame_graph = nullptr; }
+            if (++e->fg_recaptures > 8) e->use_frame_graph = 0;      // a caller that rotates its buffers: plain launches are cheaper than re-capturing
+            memcpy(e->fg_key, key, sizeof key);
+            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            capturing = true;
+        }
         // Software pipeline across the lanes: stage s of lane j starts when stage s of lane j-1 has finished, so that at any time
         // DIFFERENT stages are resident on the GPU (k_detect's sparse ring-test phases next to k_blur's FMA chains next to
         // k_describe's gathers) instead of the same stage of all lanes competing for the same unit.
@@ -423,14 +455,27 @@ int run_pipeline(jsorb_extractor *e, int n, hipEvent_t input_ready = nullptr)
         if (e->nms_ms)
             JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
                                                       e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
-        JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st));
+        JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st, direct ? e->h_counts : nullptr));
         JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
-        JSORB_STAGE(JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st));
+        JSORB_STAGE(JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st,
+                                                      direct ? Deliver{e->deliver_kp_dev, e->deliver_desc_dev, e->h_kp, e->h_desc, nullptr}
+                                                             : Deliver{nullptr, nullptr, nullptr, nullptr, nullptr}));
 #undef JSORB_STAGE
+        if (capturing) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(e, hipStreamEndCapture(st, &graph));
+            const hipError_t gi = hipGraphInstantiate(&e->frame_graph, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (gi != hipSuccess) { e->frame_graph = nullptr; e->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(gi); return JSORB_ERR_HIP; }
+            HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
+        }
         HIPCHK(e, hipGetLastError());
-        HIPCHK(e, hipMemcpyAsync(e->h_counts + f * CW, counts, sizeof(int) * CW * m, hipMemcpyDeviceToHost, st));
+        if (!direct) HIPCHK(e, hipMemcpyAsync(e->h_counts + f * CW, counts, sizeof(int) * CW * m, hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
     }
+    e->mirror_pending = direct;
+    e->deliver_kp_dev = nullptr;
+    e->deliver_desc_dev = nullptr;
     e->K = K;
     for (int j = 0; j <= K; j++) e->lane_first[j] = first[j];
     for (int j = 0; j < K; j++) e->lane_used[j] = ls[j];
@@ -481,6 +526,9 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     }
     if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));      // tuning hooks
     if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
+    if (const char *sw = getenv("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
+    if (const char *tr = getenv("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
+    if (const char *fg = getenv("JSORB_FRAME_GRAPH")) e->use_frame_graph = atoi(fg);
     if (const char *mp = getenv("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
     for (int i = 0; i < g.L; i++) {                        // needed by the LDS layout: the arg-max form needs 256 B where the literal tree needs 1 KB
         uint8_t tr[256];
@@ -536,7 +584,6 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipHostMalloc(&e->h_desc, T * 32));
     HIPCHK(e, hipHostMalloc(&e->h_u, T * sizeof(float)));
     HIPCHK(e, hipHostMalloc(&e->h_d, T * sizeof(float)));
-    e->spec_cap = (int)std::min<size_t>(T, 4096);
     {
         std::vector<uint32_t> bits;
         build_lut_bits(params->fast_n_min, params->fast_n_max, bits);
@@ -594,11 +641,18 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     return JSORB_OK;
 }
 
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 void jsorb_destroy(jsorb_extractor *e)
 {
     if (!e) return;
+    if (e->trace_host && e->th_n)
+        fprintf(stderr, "[jsorb host trace] extract x%ld: h2d enqueue %.1f us, kernel enqueue %.1f us, wait %.1f us ; stereo x%ld: enqueue %.1f us, wait %.1f us\n",
+                e->th_n, e->th_h2d / e->th_n, e->th_enq / e->th_n, e->th_wait / e->th_n, e->th_st_n, e->th_st_n ? e->th_st_enq / e->th_st_n : 0.0,
+                e->th_st_n ? e->th_st_wait / e->th_st_n : 0.0);
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    if (e->frame_graph) (void)hipGraphExecDestroy(e->frame_graph);
     for (int j = 0; j < e->K; j++)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -653,10 +707,22 @@ int jsorb_sync(jsorb_extractor *e)
 {
     if (!e) return JSORB_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
+    if (e->extracted && e->K == 1 && e->n_images == 1 && e->spin_wait) {
+        // single frame: the whole frame is ~100 us of GPU time, and a blocking hipStreamSynchronize adds tens of microseconds of wake-up
+        // latency per call (three calls per stereo frame).  Poll the stream instead (bounded), then fall through to the blocking call.
+        for (int it = 0; it < 400000; it++) {
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { e->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return JSORB_ERR_HIP; }
+            __builtin_ia32_pause();
+        }
+    }
     if (e->extracted)
         for (int j = 0; j < e->K; j++) HIPCHK(e, hipStreamSynchronize(lane_stream(e, j)));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->counts_synced = true;
+    if (e->mirror_pending) { e->mirror_valid = true; e->mirror_pending = false; }
+    if (e->st_mirror_pending) { e->st_mirror_valid = true; e->st_mirror_pending = false; }
     return drain_timed(e);
 }
 
@@ -700,9 +766,12 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
         // The buffer may still be read by an earlier batch on other lanes / by a stereo match on the other handle's stream.
         if ((rc = wait_buffer_consumed(e, 0, e->stream))) return rc;
         if ((rc = join_previous_on_main(e))) return rc;
+        const double t0 = e->trace_host ? now_us() : 0.0;
         HIPCHK(e, hipMemcpyAsync(e->stage[0], host_images, img_bytes, hipMemcpyHostToDevice, e->stream));
+        const double t1 = e->trace_host ? now_us() : 0.0;
         e->src.l0 = e->stage[0]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
         if ((rc = run_pipeline(e, n_images))) return rc;
+        if (e->trace_host) { e->th_h2d += t1 - t0; e->th_enq += now_us() - t1; e->th_n++; }
         e->stage_cur = 1;       // a following batch call starts on the other buffer
         return mark_buffer_consumed(e, 0);
     }
@@ -750,29 +819,33 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     return run_pipeline(e, n_images);
 }
 
-// Tail of the synchronous single-frame calls: speculative D2H of the first spec_cap keypoints / descriptors into the pinned
-// mirrors, ONE stream synchronisation for counts + results, remainder fetched only if this frame has more keypoints than guessed.
+// Tail of the synchronous single-frame calls: ONE stream synchronisation - counts, keypoints and descriptors were written into the
+// pinned mirrors (and the caller's device buffers) by the kernels themselves.
 static int finish_single_frame(jsorb_extractor *e, int *n_keypoints)
 {
-    const int cap = e->spec_cap;
-    HIPCHK(e, hipMemcpyAsync(e->h_kp, e->out_kp, (size_t)cap * 6 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->h_desc, e->desc, (size_t)cap * 32, hipMemcpyDeviceToHost, e->stream));
+    const double t0 = e->trace_host ? now_us() : 0.0;
     int rc = jsorb_sync(e);
+    if (e->trace_host) e->th_wait += now_us() - t0;
     if (rc) return rc;
-    const int n = e->h_counts[JSORB_MAX_LEVELS];
-    if (6 * (size_t)n > 6 * (size_t)cap) {        // the SoA is 6n contiguous ints: the prefix is in place, fetch the rest
-        HIPCHK(e, hipMemcpy(e->h_kp + (size_t)cap * 6, e->out_kp + (size_t)cap * 6, ((size_t)n - cap) * 6 * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(e->h_desc + (size_t)cap * 32, e->desc + (size_t)cap * 32, ((size_t)n - cap) * 32, hipMemcpyDeviceToHost));
-    }
-    e->mirror_valid = true;
-    e->spec_cap = std::min(e->g.T, n + n / 4 + 256);
-    if (n_keypoints) *n_keypoints = n;
+    if (n_keypoints) *n_keypoints = e->h_counts[JSORB_MAX_LEVELS];
     return JSORB_OK;
 }
 
 int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints)
 {
     int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
+    if (rc) return rc;
+    return finish_single_frame(e, n_keypoints);
+}
+
+int jsorb_extract_into(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints, int32_t *dev_keypoints_dst, uint8_t *dev_descriptors_dst)
+{
+    if (!e) return JSORB_ERR_INVALID;
+    e->deliver_kp_dev = dev_keypoints_dst;
+    e->deliver_desc_dev = dev_descriptors_dst;
+    int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
+    e->deliver_kp_dev = nullptr;
+    e->deliver_desc_dev = nullptr;
     if (rc) return rc;
     return finish_single_frame(e, n_keypoints);
 }
@@ -961,6 +1034,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     // Lane j of the left handle matches its own pairs as soon as lane j of the right handle has finished them (both handles split
     // the same n into the same lanes); with different partitions every left lane waits for all right lanes.
     const bool aligned = l->K == r->K;
+    const bool direct = n == 1;          // one pair: k_median writes uRight, depth and the statistics straight into the pinned host mirrors
     const size_t T = (size_t)l->g.T;
     const int CW = JSORB_MAX_LEVELS + 1;
     for (int j = 0; j < l->K; j++) {
@@ -975,15 +1049,14 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
         ImageSrc srcL = l->src, srcR = r->src;
         srcL.l0 += (size_t)f * srcL.l0_stride;
         srcR.l0 += (size_t)f * srcR.l0_stride;
-        HIPCHK(l, hipMemsetAsync(l->st_stats + f * 8, 0, sizeof(int) * 8 * m, st));
         TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, srcL, l->slab + (size_t)f * l->g.slab_bytes, srcR, r->slab + (size_t)f * r->g.slab_bytes,
                                               l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_len,
                                               l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st));
         TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
-                                              l->st_stats + f * 8, m, st));
+                                              l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, nullptr}));
         HIPCHK(l, hipGetLastError());
-        HIPCHK(l, hipMemcpyAsync(l->h_stats + f * 8, l->st_stats + f * 8, sizeof(int) * 8 * m, hipMemcpyDeviceToHost, st));
+        if (!direct) HIPCHK(l, hipMemcpyAsync(l->h_stats + f * 8, l->st_stats + f * 8, sizeof(int) * 8 * m, hipMemcpyDeviceToHost, st));
         HIPCHK(l, hipEventRecord(l->lane_done[j], st));
         if (r != l) { HIPCHK(l, hipEventRecord(r->lane_readers_done[j], st)); r->readers_stream[j] = st; }
         // the L1 refinement reads both level-0 planes in place: a landing buffer is free for the next upload only after this point
@@ -1000,6 +1073,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     }
     l->stereo_done = true;
     l->st_mirror_valid = false;
+    l->st_mirror_pending = direct;
     l->stereo_pairs = n;
     l->counts_synced = false;
     return JSORB_OK;
@@ -1061,18 +1135,13 @@ int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float m
                        float *depth, jsorb_stereo_stats *stats)
 {
     if (!l || !r) return JSORB_ERR_INVALID;
-    l->counts_synced_before_stereo = l->counts_synced;
+    const double t0 = l->trace_host ? now_us() : 0.0;
     int rc = jsorb_stereo_match_batch_async(l, r, mb, mbf, th_high, th_low);
     if (rc) return rc;
-    // the speculative copy is sized from the host-side count, which is only current if the extract was a synchronous call
-    const int n = l->counts_synced_before_stereo ? jsorb_n_keypoints(l, 0) : 0;
-    if (l->n_images == 1 && n > 0) {              // results ride in the same round trip as the statistics
-        HIPCHK(l, hipMemcpyAsync(l->h_u, l->st_u, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, l->stream));
-        HIPCHK(l, hipMemcpyAsync(l->h_d, l->st_d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, l->stream));
-    }
+    const double t1 = l->trace_host ? now_us() : 0.0;
     rc = jsorb_sync(l);
     if (rc) return rc;
-    l->st_mirror_valid = l->n_images == 1 && n > 0;
+    if (l->trace_host) { l->th_st_enq += t1 - t0; l->th_st_wait += now_us() - t1; l->th_st_n++; }
     rc = jsorb_copy_stereo(l, 0, u_right, depth, stats);
     if (rc) return rc;
     if (stats) stats->n_right = jsorb_n_keypoints(r, 0);

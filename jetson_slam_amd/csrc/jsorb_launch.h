@@ -27,12 +27,12 @@ void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, 
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
-                    int *row_tab, int n_images, hipStream_t s);
+                    int *row_tab, int n_images, hipStream_t s, int *counts_host = nullptr);
 void blur_tile_dims(int *tw, int *th);     // k_blur's workgroup tile (host-side launch table)
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s);
 void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *blur_slab,
                      const unsigned long long *kp, const int *counts, float *angles, uint8_t *desc, int32_t *out_kp,
-                     int n_images, hipStream_t s);
+                     int n_images, hipStream_t s, Deliver dl = Deliver{nullptr, nullptr, nullptr, nullptr, nullptr});
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
@@ -42,6 +42,6 @@ void launch_assign_grid(const int32_t *soa, int n, float min_x, float min_y, flo
                         int32_t *cell_start, int32_t *cell_items, hipStream_t s);
 void launch_gather_counts(const int *countsL, const int *countsR, const int *stats, int32_t *dst, int n_pairs, hipStream_t s);
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
-                   int *stats, int n_pairs, hipStream_t s);
+                   int *stats, int n_pairs, hipStream_t s, DeliverStereo dl = DeliverStereo{nullptr, nullptr, nullptr});
 
 } // namespace jsorb

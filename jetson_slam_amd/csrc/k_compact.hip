@@ -12,7 +12,7 @@ namespace jsorb {
 
 __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned long long *__restrict__ tile_out,
                                                   unsigned long long *__restrict__ kp, int *__restrict__ counts,
-                                                  int *__restrict__ row_tab)
+                                                  int *__restrict__ row_tab, int *__restrict__ counts_host)
 {
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,9 +50,13 @@ __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned lon
         if (tid == 0) {
             rt[lv.row_tab_off + lv.nth] = base;
             counts[b * (JSORB_MAX_LEVELS + 1) + lvl] = base - level_start;
+            if (counts_host) counts_host[b * (JSORB_MAX_LEVELS + 1) + lvl] = base - level_start;
         }
     }
-    if (tid == 0) counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = base;
+    if (tid == 0) {
+        counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = base;
+        if (counts_host) counts_host[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = base;
+    }
 }
 
 // Flat form for T <= 65536 candidates: one pass stores the wave ballots of all 1024-entry chunks, one workgroup prefix scan turns
@@ -69,7 +73,7 @@ __device__ __forceinline__ int compact_pos_of(int j, int T, int total, const uns
 
 __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigned long long *__restrict__ tile_out,
                                                        unsigned long long *__restrict__ kp, int *__restrict__ counts,
-                                                       int *__restrict__ row_tab)
+                                                       int *__restrict__ row_tab, int *__restrict__ counts_host)
 {
     __shared__ unsigned long long s_bal[CMP_MAX_CHUNKS * 16];
     __shared__ int s_base[CMP_MAX_CHUNKS * 16];
@@ -129,18 +133,23 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     }
     if (tid < g.L) {
         const int j0 = g.lv[tid].tile_off, j1 = tid + 1 < g.L ? g.lv[tid + 1].tile_off : T;
-        counts[b * (JSORB_MAX_LEVELS + 1) + tid] = compact_pos_of(j1, T, total, s_bal, s_base) - compact_pos_of(j0, T, total, s_bal, s_base);
+        const int c = compact_pos_of(j1, T, total, s_bal, s_base) - compact_pos_of(j0, T, total, s_bal, s_base);
+        counts[b * (JSORB_MAX_LEVELS + 1) + tid] = c;
+        if (counts_host) counts_host[b * (JSORB_MAX_LEVELS + 1) + tid] = c;
     }
-    if (tid == 0) counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = total;
+    if (tid == 0) {
+        counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = total;
+        if (counts_host) counts_host[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = total;
+    }
 }
 
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
-                    int *row_tab, int n_images, hipStream_t s)
+                    int *row_tab, int n_images, hipStream_t s, int *counts_host)
 {
     if (g.T <= CMP_MAX_CHUNKS * 1024)
-        hipLaunchKernelGGL(k_compact_flat, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab);
+        hipLaunchKernelGGL(k_compact_flat, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab, counts_host);
     else
-        hipLaunchKernelGGL(k_compact, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab);
+        hipLaunchKernelGGL(k_compact, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab, counts_host);
 }
 
 } // namespace jsorb

@@ -29,6 +29,11 @@ namespace jsorb {
 // LDS image row stride (bytes).  A tile group is at most 128 px wide; + 4 px halo each side + <= 15 alignment bytes <= 151.
 // A compile-time stride turns the 16 ring offsets of phase 2 into immediate LDS offsets.
 #define DET_S 160
+// survivor-list capacity of one wave (entries) and the most entries one early-reject step appends (4 pixel slots x 64 lanes)
+#ifndef DET_LIST_CAP
+#define DET_LIST_CAP 640
+#endif
+#define DET_LIST_STEP 256
 
 struct DetectLds {
     int img_stride;      // bytes per LDS image row (multiple of 16)
@@ -47,7 +52,12 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     d.img_rows = th + 8;
     d.score_w = ktw + 2;
     d.score_rows = th + 2;
-    d.list_cap = 2 * ((d.score_rows + 7) / 8) * d.score_w;      // a wave owns <= 2*ceil(rows/8) rows of the score region
+    // a wave owns <= 2*ceil(rows/8) rows of the score region.  The list is CAPPED (the worst case - every pixel survives the early
+    // rejects - would cost 7.8 KB at tile 30 and hold the kernel at 7 workgroups per CU): when a wave's list could not take another
+    // early-reject step (DET_LIST_STEP entries), the wave runs its ring test on what it has - only positives stay in the list - and
+    // goes on; if even the positives do not fit, the wave falls back to a dense scan of its rows in phase 3.
+    const int full = 2 * ((d.score_rows + 7) / 8) * d.score_w;
+    d.list_cap = full <= DET_LIST_CAP ? full : DET_LIST_CAP;
     size_t o = (size_t)d.img_stride * d.img_rows;
     o = (o + 15) & ~(size_t)15;
     d.off_score = o;
@@ -182,7 +192,65 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     const int thc = min(threshold, 256);
     const s2 th_pk = (s2){(short)thc, (short)thc};
 #define PK(hi, lo, sel) __builtin_bit_cast(s2, __builtin_amdgcn_perm((hi), (lo), (sel)))
-    for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += 4 * rows_per_step) {
+    // Phases 1 and 2 share one loop: early-reject steps append to the wave's list; when the list could not take another step (or the
+    // wave has done all its rows) the ring test runs on the pending entries [n_pos, n_mine) and leaves only positives [0, n_pos).
+    const int lx_off = c0;
+    const int min_pop = g.lut_min_pop;
+    const int flush_at = L.list_cap - DET_LIST_STEP;      // wave-uniform; never exceeded when the list holds the worst case
+    int n_pos = 0;                                        // wave-uniform: positives at the front of the list
+    bool dense = false;                                   // wave-uniform: the positives overflowed, phase 3 scans this wave's rows densely
+    for (int rbase = wave * rows_per_step;; rbase += 4 * rows_per_step) {
+        const bool p1_done = rbase >= L.score_rows;
+        if (p1_done || n_mine > flush_at) {
+            // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
+            // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
+            // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
+            for (int i0 = n_pos; i0 < n_mine; i0 += 64) {
+                const int i = i0 + lane;
+                bool hit = false;
+                int e = 0;
+                if (i < n_mine) {
+                    e = my_list[i];
+                    const int ry = e >> 8, rx = e & 255;
+                    const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
+                    const int v = c[0], vt = v + threshold, v_t = v - threshold;
+                    int p[16];
+                    p[0] = c[3 * S];       p[1] = c[3 * S + 1];   p[2] = c[2 * S + 2];   p[3] = c[S + 3];
+                    p[4] = c[3];           p[5] = c[-S + 3];      p[6] = c[-2 * S + 2];  p[7] = c[-3 * S + 1];
+                    p[8] = c[-3 * S];      p[9] = c[-3 * S - 1];  p[10] = c[-2 * S - 2]; p[11] = c[-S - 3];
+                    p[12] = c[-3];         p[13] = c[S - 3];      p[14] = c[2 * S - 2];  p[15] = c[3 * S - 1];
+                    // brighter / darker masks, bit k = ring pixel k.  Two VALU per bit and no SGPR round trip: the sign bit of
+                    // (vt - p) [p > vt] or (p - v_t) [p < v_t] is shifted into the mask with one v_alignbit_b32.
+                    unsigned bright = 0, dark = 0;
+#pragma unroll
+                    for (int k = 15; k >= 0; k--) {
+                        bright = __builtin_amdgcn_alignbit(bright, (unsigned)(vt - p[k]), 31);
+                        dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p[k] - v_t), 31);
+                    }
+                    // arc LUT (8 KB bit table, global): a divergent dword gather costs the vector-memory pipeline ~1 lane/clk, so masks
+                    // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
+                    // of them is ever looked up, usually none)
+                    unsigned lb = 0;
+                    if (__popc(bright) >= min_pop) lb = lut_bits[bright >> 5] >> (bright & 31);
+                    if (__popc(dark) >= min_pop) lb |= lut_bits[dark >> 5] >> (dark & 31);
+                    hit = (lb & 1u) != 0;
+                    if (hit) {
+                        const unsigned v4 = (unsigned)v * 0x01010101u;
+                        unsigned sad = 0;
+#pragma unroll
+                        for (int k = 0; k < 16; k += 4)
+                            sad = __builtin_amdgcn_sad_u8((unsigned)p[k] | ((unsigned)p[k + 1] << 8) | ((unsigned)p[k + 2] << 16) | ((unsigned)p[k + 3] << 24), v4, sad);
+                        s_score[ry * L.score_w + rx] = (unsigned short)sad;
+                    }
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (hit && !dense) my_list[n_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                n_pos += __popcll(bal);
+            }
+            if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
+            n_mine = n_pos;
+            if (p1_done) break;
+        }
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
         const bool row_ok = ry < L.score_rows && y >= JSORB_BORDER && y < H - JSORB_BORDER;
@@ -234,57 +302,10 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     }
 #undef PK
 
-    // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
-    // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
-    // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
-    const int lx_off = c0;
-    const int min_pop = g.lut_min_pop;
-    int n_pos = 0;                                        // wave-uniform
-    for (int i0 = 0; i0 < n_mine; i0 += 64) {
-        const int i = i0 + lane;
-        bool hit = false;
-        int e = 0;
-        if (i < n_mine) {
-            e = my_list[i];
-            const int ry = e >> 8, rx = e & 255;
-            const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
-            const int v = c[0], vt = v + threshold, v_t = v - threshold;
-            int p[16];
-            p[0] = c[3 * S];       p[1] = c[3 * S + 1];   p[2] = c[2 * S + 2];   p[3] = c[S + 3];
-            p[4] = c[3];           p[5] = c[-S + 3];      p[6] = c[-2 * S + 2];  p[7] = c[-3 * S + 1];
-            p[8] = c[-3 * S];      p[9] = c[-3 * S - 1];  p[10] = c[-2 * S - 2]; p[11] = c[-S - 3];
-            p[12] = c[-3];         p[13] = c[S - 3];      p[14] = c[2 * S - 2];  p[15] = c[3 * S - 1];
-            // brighter / darker masks, bit k = ring pixel k.  Two VALU per bit and no SGPR round trip: the sign bit of
-            // (vt - p) [p > vt] or (p - v_t) [p < v_t] is shifted into the mask with one v_alignbit_b32.
-            unsigned bright = 0, dark = 0;
-#pragma unroll
-            for (int k = 15; k >= 0; k--) {
-                bright = __builtin_amdgcn_alignbit(bright, (unsigned)(vt - p[k]), 31);
-                dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p[k] - v_t), 31);
-            }
-            // arc LUT (8 KB bit table, global): a divergent dword gather costs the vector-memory pipeline ~1 lane/clk, so masks
-            // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
-            // of them is ever looked up, usually none)
-            unsigned lb = 0;
-            if (__popc(bright) >= min_pop) lb = lut_bits[bright >> 5] >> (bright & 31);
-            if (__popc(dark) >= min_pop) lb |= lut_bits[dark >> 5] >> (dark & 31);
-            hit = (lb & 1u) != 0;
-            if (hit) {
-                const unsigned v4 = (unsigned)v * 0x01010101u;
-                unsigned sad = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k += 4)
-                    sad = __builtin_amdgcn_sad_u8((unsigned)p[k] | ((unsigned)p[k + 1] << 8) | ((unsigned)p[k + 2] << 16) | ((unsigned)p[k + 3] << 24), v4, sad);
-                s_score[ry * L.score_w + rx] = (unsigned short)sad;
-            }
-        }
-        const unsigned long long bal = __ballot(hit);
-        if (hit) my_list[n_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
-        n_pos += __popcll(bal);
-    }
     __syncthreads();
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + arg-max key, positives of the wave's own list ----
+    // (list entries always have a positive score; the `s > 0` test only matters for the dense fallback)
     // K3 picks, per tile, the maximum score; ties go first to the column the horizontal tree prefers, then inside the column to
     // the smaller (ty, k).  When the host has verified that the tree is an arg-max with a fixed column priority (tree_rank_ok),
     // one ds_max_u32 per positive on a per-TILE key (score << 18 | 127 - column priority << 11 | 2047 - row rank) yields the
@@ -293,14 +314,13 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     const int n_ty = lv.n_ty, recip_nty = (65536 + n_ty - 1) / n_ty, recip_tw = (65536 + tw - 1) / tw;
     const bool ranked = lv.tree_rank_ok != 0;
     const unsigned char *s_rank = reinterpret_cast<const unsigned char *>(s_tree);      // rank[128], inv[128]
-    for (int i = lane; i < n_pos; i += 64) {
-        const int e = my_list[i], ry = e >> 8, rx = e & 255;
-        if (ry < 1 || ry > th || rx < 1 || rx > ktw) continue;        // halo entries only serve as neighbours
+    auto nms_one = [&](int ry, int rx) {
+        if (ry < 1 || ry > th || rx < 1 || rx > ktw) return;          // halo entries only serve as neighbours
         const unsigned short *q = s_score + ry * SW + rx;
         const int s = q[0];
-        const bool valid = s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
+        const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
                            s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];
-        if (!valid) continue;
+        if (!valid) return;
         const int dy = ry - 1;
         const int kk = (dy * recip_nty) >> 16, ty = dy - kk * n_ty;      // dy / n_ty, exact for dy < 8192 (n_ty <= 8)
         const unsigned rank = (unsigned)(ty * 256 + kk);                 // lexicographic (ty, k); k < mini_tile <= 128
@@ -310,6 +330,18 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         } else {
             atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
         }
+    };
+    if (!dense) {
+        for (int i = lane; i < n_pos; i += 64) {
+            const int e = my_list[i];
+            nms_one(e >> 8, e & 255);
+        }
+    } else {
+        // the wave's positives did not fit its list (a tile of almost nothing but corners): every pixel of the rows this wave owned
+        // in phase 1 is looked at; s_score holds 0 wherever there is no corner
+        for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += 4 * rows_per_step)
+            for (int ry = rbase; ry < rbase + rows_per_step && ry < L.score_rows; ry++)
+                for (int rx = lane; rx < SW; rx += 64) nms_one(ry, rx);
     }
     __syncthreads();
 

@@ -269,17 +269,17 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
 // generic form (any number of keypoints): three passes over the distances in memory, bin searches by thread 0
 __device__ __noinline__ void median_big(const Geometry &g, const int *__restrict__ countsL, float *__restrict__ u_right,
                                                 float *__restrict__ depth, const int *__restrict__ best_l1,
-                                                const unsigned *__restrict__ aux, int *__restrict__ stats)
+                                                const unsigned *__restrict__ aux, int *__restrict__ stats, DeliverStereo dl)
 {
     __shared__ int hist[256];
     __shared__ int sel[4];
-    __shared__ int s_cand, s_corr;
+    __shared__ int s_cand, s_corr, s_removed;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     const size_t tb = (size_t)b * g.T;
     int *st = stats + b * 8;
     hist[tid] = 0;
-    if (tid == 0) { s_cand = 0; s_corr = 0; }
+    if (tid == 0) { s_cand = 0; s_corr = 0; s_removed = 0; }
     __syncthreads();
     int cand = 0, corr = 0;
     for (int i = tid; i < Nl; i += 256) {
@@ -293,7 +293,6 @@ __device__ __noinline__ void median_big(const Geometry &g, const int *__restrict
     corr = wave_sum_i32(corr);
     if ((tid & 63) == 0) { atomicAdd(&s_cand, cand); atomicAdd(&s_corr, corr); }
     __syncthreads();
-    if (tid == 0) { st[0] = s_cand; st[1] = s_corr; }
     if (tid == 0) {
         int nv = 0;
         for (int k = 0; k < 256; k++) nv += hist[k];
@@ -308,42 +307,47 @@ __device__ __noinline__ void median_big(const Geometry &g, const int *__restrict
     }
     __syncthreads();
     const int nv = sel[2];
-    if (tid == 0) st[2] = nv;
-    if (nv == 0) {              // Appendix C-6: nothing matched -> no cut
-        if (tid == 0) st[3] = 0;
-        return;
-    }
-    const int bin = sel[0], kin = sel[1];
-    __syncthreads();
-    hist[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < Nl; i += 256) {
-        const int d = best_l1[tb + i];
-        if (d >= 0 && ((d >> 8) & 255) == bin) atomicAdd(&hist[d & 255], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int cum = 0, low = 0;
-        for (int k = 0; k < 256; k++) {
-            if (cum + hist[k] > kin) { low = k; break; }
-            cum += hist[k];
+    float thDist = 3.0e38f;     // Appendix C-6: nothing matched -> no cut
+    if (nv > 0) {
+        const int bin = sel[0], kin = sel[1];
+        __syncthreads();
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < Nl; i += 256) {
+            const int d = best_l1[tb + i];
+            if (d >= 0 && ((d >> 8) & 255) == bin) atomicAdd(&hist[d & 255], 1);
         }
-        sel[3] = (bin << 8) | low;
-        st[3] = nv;
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, low = 0;
+            for (int k = 0; k < 256; k++) {
+                if (cum + hist[k] > kin) { low = k; break; }
+                cum += hist[k];
+            }
+            sel[3] = (bin << 8) | low;
+        }
+        __syncthreads();
+        const float median = (float)sel[3];
+        thDist = 1.5f * 1.4f * median;
     }
-    __syncthreads();
-    const float median = (float)sel[3];
-    const float thDist = 1.5f * 1.4f * median;
     int removed = 0;
     for (int i = tid; i < Nl; i += 256) {
         const int d = best_l1[tb + i];
+        float u = u_right[tb + i], z = depth[tb + i];
         if (d >= 0 && !((float)d < thDist)) {
-            u_right[tb + i] = -1.0f;
-            depth[tb + i] = -1.0f;
+            u = -1.0f; z = -1.0f;
+            u_right[tb + i] = u;
+            depth[tb + i] = z;
             removed++;
         }
+        if (dl.u_host) { dl.u_host[i] = u; dl.d_host[i] = z; }
     }
-    if (removed) atomicSub(&st[3], removed);
+    if (removed) atomicAdd(&s_removed, removed);
+    __syncthreads();
+    if (tid == 0) {
+        const int v[4] = {s_cand, s_corr, nv, nv - s_removed};
+        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[k] = v[k]; }
+    }
 }
 
 // exclusive prefix of one value per thread over the 256 threads of the workgroup (s_w: 4 ints of LDS scratch); also returns the total
@@ -366,22 +370,22 @@ __device__ __forceinline__ int block256_exclusive_scan(int v, int *s_w, int &tot
 #define MED_R 32
 __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restrict__ countsL, float *__restrict__ u_right,
                                                 float *__restrict__ depth, const int *__restrict__ best_l1,
-                                                const unsigned *__restrict__ aux, int *__restrict__ stats)
+                                                const unsigned *__restrict__ aux, int *__restrict__ stats, DeliverStereo dl)
 {
     __shared__ int hist[256];
     __shared__ int sel[4];
     __shared__ int s_w[4];
-    __shared__ int s_cand, s_corr;
+    __shared__ int s_cand, s_corr, s_removed;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     const size_t tb = (size_t)b * g.T;
     int *st = stats + b * 8;
     if (Nl > 256 * MED_R) {                                // wave-uniform: too many keypoints for the register-resident form
-        median_big(g, countsL, u_right, depth, best_l1, aux, stats);
+        median_big(g, countsL, u_right, depth, best_l1, aux, stats, dl);
         return;
     }
     hist[tid] = 0;
-    if (tid == 0) { s_cand = 0; s_corr = 0; }
+    if (tid == 0) { s_cand = 0; s_corr = 0; s_removed = 0; }
     int d[MED_R];
     int cand = 0, corr = 0;
 #pragma unroll
@@ -403,7 +407,6 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
     corr = wave_sum_i32(corr);
     if ((tid & 63) == 0) { atomicAdd(&s_cand, cand); atomicAdd(&s_corr, corr); }
     __syncthreads();
-    if (tid == 0) { st[0] = s_cand; st[1] = s_corr; }
     // the (nv/2)-th smallest distance: bin of the high byte, then of the low byte inside that bin
     int nv;
     {
@@ -412,39 +415,60 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
         const int kth = nv / 2;
         if (h > 0 && excl <= kth && kth < excl + h) { sel[0] = tid; sel[1] = kth - excl; }      // exactly one bin (nv > 0)
     }
-    if (tid == 0) st[2] = nv;
-    if (nv == 0) {              // Appendix C-6: nothing matched -> no cut
-        if (tid == 0) st[3] = 0;
-        return;
-    }
-    hist[tid] = 0;
-    __syncthreads();
-    const int bin = sel[0], kin = sel[1];
+    float thDist = 3.0e38f;     // Appendix C-6: nothing matched -> no cut (nv is workgroup-uniform)
+    if (nv > 0) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int bin = sel[0], kin = sel[1];
 #pragma unroll
-    for (int r = 0; r < MED_R; r++)
-        if (d[r] >= 0 && ((d[r] >> 8) & 255) == bin) atomicAdd(&hist[d[r] & 255], 1);
-    __syncthreads();
-    {
-        const int h = hist[tid];
-        int tot;
-        const int excl = block256_exclusive_scan(h, s_w, tot);
-        if (h > 0 && excl <= kin && kin < excl + h) sel[3] = (bin << 8) | tid;
-        if (tid == 0) st[3] = nv;
+        for (int r = 0; r < MED_R; r++)
+            if (d[r] >= 0 && ((d[r] >> 8) & 255) == bin) atomicAdd(&hist[d[r] & 255], 1);
+        __syncthreads();
+        {
+            const int h = hist[tid];
+            int tot;
+            const int excl = block256_exclusive_scan(h, s_w, tot);
+            if (h > 0 && excl <= kin && kin < excl + h) sel[3] = (bin << 8) | tid;
+        }
+        __syncthreads();
+        const float median = (float)sel[3];
+        thDist = 1.5f * 1.4f * median;
     }
-    __syncthreads();
-    const float median = (float)sel[3];
-    const float thDist = 1.5f * 1.4f * median;
     int removed = 0;
+    if (dl.u_host) {            // single-pair call: the final uRight / depth also go to the pinned host mirror
+#pragma unroll 4
+        for (int r = 0; r < MED_R; r++) {
+            const int i = tid + 256 * r;
+            if (i < Nl) {
+                float u = u_right[tb + i], z = depth[tb + i];
+                if (d[r] >= 0 && !((float)d[r] < thDist)) {
+                    u = -1.0f; z = -1.0f;
+                    u_right[tb + i] = u;
+                    depth[tb + i] = z;
+                    removed++;
+                }
+                dl.u_host[i] = u;
+                dl.d_host[i] = z;
+            }
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < MED_R; r++) {
-        const int i = tid + 256 * r;
-        if (d[r] >= 0 && !((float)d[r] < thDist)) {
-            u_right[tb + i] = -1.0f;
-            depth[tb + i] = -1.0f;
-            removed++;
+        for (int r = 0; r < MED_R; r++) {
+            const int i = tid + 256 * r;
+            if (d[r] >= 0 && !((float)d[r] < thDist)) {
+                u_right[tb + i] = -1.0f;
+                depth[tb + i] = -1.0f;
+                removed++;
+            }
         }
     }
-    if (removed) atomicSub(&st[3], removed);
+    if (removed) atomicAdd(&s_removed, removed);
+    __syncthreads();
+    if (tid == 0) {
+        const int v[4] = {s_cand, s_corr, nv, nv - s_removed};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[k] = v[k]; }
+    }
 }
 
 __global__ void k_gather_counts(const int *__restrict__ countsL, const int *__restrict__ countsR, const int *__restrict__ stats,
@@ -472,9 +496,9 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
 }
 
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
-                   int *stats, int n_pairs, hipStream_t s)
+                   int *stats, int n_pairs, hipStream_t s, DeliverStereo dl)
 {
-    hipLaunchKernelGGL(k_median, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, aux, stats);
+    hipLaunchKernelGGL(k_median, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, aux, stats, dl);
 }
 
 } // namespace jsorb

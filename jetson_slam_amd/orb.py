@@ -22,7 +22,7 @@ TH_HIGH, TH_LOW = 100, 50   # ORBmatcher::TH_HIGH / TH_LOW, src/ORBmatcher.cpp:2
 KERNELS = ["k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median", "k_nms_ms"]
 
 EXPORTS = [
-    "jsorb_create", "jsorb_destroy", "jsorb_last_error", "jsorb_version", "jsorb_extract", "jsorb_extract_device",
+    "jsorb_create", "jsorb_destroy", "jsorb_last_error", "jsorb_version", "jsorb_extract", "jsorb_extract_into", "jsorb_extract_device",
     "jsorb_extract_batch_device_async", "jsorb_extract_batch_host_async", "jsorb_sync", "jsorb_n_images", "jsorb_n_keypoints",
     "jsorb_level_n_keypoints", "jsorb_keypoints_device", "jsorb_descriptors_device", "jsorb_copy_keypoints",
     "jsorb_copy_descriptors", "jsorb_n_levels", "jsorb_level_dims", "jsorb_level_tiles", "jsorb_total_tiles", "jsorb_scale",
@@ -77,6 +77,7 @@ def load_library(path=None):
         "jsorb_last_error": (C.c_char_p, [P]),
         "jsorb_version": (C.c_char_p, []),
         "jsorb_extract": (I, [P, P, I, C.POINTER(I)]),
+        "jsorb_extract_into": (I, [P, P, I, C.POINTER(I), P, P]),
         "jsorb_extract_device": (I, [P, P, I, C.POINTER(I)]),
         "jsorb_extract_batch_device_async": (I, [P, P, C.c_size_t, I, I]),
         "jsorb_extract_batch_host_async": (I, [P, P, C.c_size_t, I, I]),

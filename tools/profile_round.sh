@@ -8,7 +8,7 @@ O=$ROOT/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-B="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-steps 0 --single-stream"   # one stream: per-kernel durations are not inflated by left/right overlap
+B="python $ROOT/bench.py --steps 10 --warmup 2 --min-time 0 --no-cpu-baseline --no-extras --profile-steps 0 --single-stream"   # one stream: per-kernel durations are not inflated by left/right overlap
 rm -rf $O/${TAG}_trace $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o t -- $B > $O/${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o p -- $B > $O/${TAG}_fetch.log 2>&1
