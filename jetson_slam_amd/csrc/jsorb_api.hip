@@ -184,7 +184,8 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         // this build's workgroup tables
         lv.k_tiles = std::max(1, 122 / lv.tw);   // k*tw + 2 <= 124: a score-region row fits 32 aligned LDS dwords (k_detect phase 1)
         lv.groups_per_row = (lv.ntw - 1) / lv.k_tiles + 1;
-        lv.detect_blk0 = dblk;
+        lv.det_R = 1;
+        lv.detect_blk0 = dblk;           // provisional: fill_detect_layout() may put several tile rows into one workgroup
         dblk += lv.nth * lv.groups_per_row;
         lv.row_tab_off = rtab;
         rtab += lv.nth + 1;
@@ -605,7 +606,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         blur_tile_dims(&btw, &bth);
         for (int i = 0; i < g.L; i++) {
             const LevelDesc &lv = g.lv[i];
-            for (int r = 0; r < lv.nth; r++)
+            for (int r = 0; r < (lv.nth + lv.det_R - 1) / lv.det_R; r++)          // r: group of det_R tile rows
                 for (int gr = 0; gr < lv.groups_per_row; gr++)
                     bits[CTAB_DETECT + lv.detect_blk0 + r * lv.groups_per_row + gr] = (uint32_t)i | ((uint32_t)r << 4) | ((uint32_t)gr << 18);
             for (int by = 0; by < lv.blur_by; by++)

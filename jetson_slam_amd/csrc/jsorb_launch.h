@@ -22,7 +22,7 @@ size_t detect_lds_bytes(const Geometry &g);
 size_t pyramid_lds_bytes(const Geometry &g);
 size_t pyramid_window_bytes(float s, int rows_out);      // LDS bytes of the level-0 window of one k_pyramid tile
 void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, const uint32_t *ctab, int n_images, size_t lds_bytes, hipStream_t s);
-void fill_detect_layout(Geometry &g);      // per-level LDS layout of k_detect (host side, once per handle)
+void fill_detect_layout(Geometry &g);      // tile rows per workgroup (det_R), workgroup table offsets and per-level LDS layout of k_detect (host side, once per handle)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);

@@ -22,6 +22,9 @@
 //   * phase 3 (positive scores only): 3x3 NMS from LDS and one ds_max_u32 per column with the key
 //     (score << 16 | 0xFFFF - rank), rank = ty * 256 + k : the max key IS the reference's column winner.
 //   * phase 4: the reference's horizontal tree replayed literally on <= 128 column slots in LDS.
+#include <algorithm>
+#include <cstdlib>
+
 #include "jsorb_launch.h"
 
 namespace jsorb {
@@ -74,21 +77,38 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     return d;
 }
 
+// Tile rows per workgroup.  The launch-wide LDS size is set by the level with the largest tiles (level 0 unless the tile size is
+// fixed); the levels above it have smaller tiles and their workgroups would leave most of that allocation unused while paying the
+// same fixed cost (scalar prologue, staging passes, barriers, list bookkeeping - about 150 VALU + 500 SALU per wave, a third of a
+// wave's instructions at 8-row tiles).  Those levels put as many tile rows into one workgroup as fit into the SAME allocation.
+#define DET_MAX_R 4
 void fill_detect_layout(Geometry &g)
 {
+    size_t budget = 0;
+    for (int i = 0; i < g.L; i++) budget = std::max(budget, detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok).total);
+    int dblk = 0;
     for (int i = 0; i < g.L; i++) {
         LevelDesc &lv = g.lv[i];
-        const DetectLds d = detect_lds_layout(lv.th, lv.tw, lv.k_tiles, lv.tree_rank_ok);
+        int R = 1;
+        // only the arg-max form of the tile reduction (tree_rank_ok) handles several tile rows; keys: R * k_tiles <= 128 slots, row index < 256
+        while (lv.tree_rank_ok && R < DET_MAX_R && R < lv.nth && (R + 1) * lv.k_tiles <= 128 && (R + 1) * lv.th + 2 <= 255 &&
+               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1).total <= budget && !getenv("JSORB_DETECT_NO_BANDS"))
+            R++;
+        lv.det_R = R;
+        lv.detect_blk0 = dblk;
+        dblk += ((lv.nth + R - 1) / R) * lv.groups_per_row;
+        const DetectLds d = detect_lds_layout(R * lv.th, lv.tw, lv.k_tiles, lv.tree_rank_ok);
         lv.det_score_w = d.score_w; lv.det_score_rows = d.score_rows; lv.det_img_rows = d.img_rows; lv.det_list_cap = d.list_cap;
         lv.det_off_score = (int)d.off_score; lv.det_off_list = (int)d.off_list; lv.det_off_colkey = (int)d.off_colkey; lv.det_off_tree = (int)d.off_tree;
     }
+    g.detect_blocks = dblk;
 }
 
 size_t detect_lds_bytes(const Geometry &g)
 {
     size_t m = 0;
     for (int i = 0; i < g.L; i++) {
-        DetectLds d = detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok);
+        DetectLds d = detect_lds_layout(g.lv[i].det_R * g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok);
         if (d.total > m) m = d.total;
     }
     return m;
@@ -110,11 +130,12 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     const unsigned wd = ctab_load(lut_bits, CTAB_DETECT + blk);
     const int lvl = (int)(wd & 15u), r = (int)((wd >> 4) & 0x3FFFu), grp = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
-    const int H = lv.H, W = lv.W, th = lv.th, tw = lv.tw;
-    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(lv.det_img_rows), "s"(H), "s"(th));       // one round of loads
+    const int H = lv.H, W = lv.W, th1 = lv.th, tw = lv.tw, R = lv.det_R;
+    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(lv.det_img_rows), "s"(H), "s"(th1), "s"(R));       // one round of loads
+    const int th = R * th1;               // rows of the band: R tile rows of th1 rows each (R = 1 on the levels with the largest tiles)
     const int ktw = lv.k_tiles * tw;
     const int xg0 = grp * ktw;            // first image column of the tile group
-    const int y0 = r * th;                // first image row of the tile row
+    const int y0 = r * th;                // first image row of the band
     DetectLds L;
     L.img_stride = DET_S; L.img_rows = lv.det_img_rows; L.score_w = lv.det_score_w; L.score_rows = lv.det_score_rows; L.list_cap = lv.det_list_cap;
     L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
@@ -321,12 +342,16 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
                            s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];
         if (!valid) return;
-        const int dy = ry - 1;
+        int dy = ry - 1, trow = 0;                                       // tile row inside the band and row inside that tile (R <= 4)
+        if (R > 1) {
+            trow = (dy >= th1) + (dy >= 2 * th1) + (dy >= 3 * th1);
+            dy -= trow * th1;
+        }
         const int kk = (dy * recip_nty) >> 16, ty = dy - kk * n_ty;      // dy / n_ty, exact for dy < 8192 (n_ty <= 8)
         const unsigned rank = (unsigned)(ty * 256 + kk);                 // lexicographic (ty, k); k < mini_tile <= 128
         if (ranked) {
             const int tile = ((rx - 1) * recip_tw) >> 16, cit = rx - 1 - tile * tw;      // (rx-1) / tw, exact for rx-1 < 512
-            atomicMax(&s_colkey[tile], ((unsigned)s << 18) | ((127u - s_rank[cit]) << 11) | (2047u - rank));
+            atomicMax(&s_colkey[trow * lv.k_tiles + tile], ((unsigned)s << 18) | ((127u - s_rank[cit]) << 11) | (2047u - rank));
         } else {
             atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
         }
@@ -347,16 +372,20 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 
     if (ranked) {
         // ---- phase 4 (arg-max form): one thread per tile decodes the winner ----
-        if (tid < lv.k_tiles && xg0 + tid * tw < W) {
+        const int kt = lv.k_tiles;
+        const int trow = (tid >= kt) + (tid >= 2 * kt) + (tid >= 3 * kt), tcol = tid - trow * kt;      // R <= 4 tile rows of kt tiles
+        const int tr = r * R + trow;                      // tile row in the level
+        if (tid < R * kt && tr < lv.nth && xg0 + tcol * tw < W) {
             const unsigned key = s_colkey[tid];
             const int sc = (int)(key >> 18);
-            int xx = xg0 + tid * tw, yy = y0;             // nothing positive: the tree keeps slot 0's initial value
+            const int yt0 = y0 + trow * th1;
+            int xx = xg0 + tcol * tw, yy = yt0;           // nothing positive: the tree keeps slot 0's initial value
             if (sc > 0) {
                 const int rr = (int)(2047u - (key & 2047u));
                 xx += s_rank[128 + (127 - (int)((key >> 11) & 127u))];
-                yy = y0 + (rr >> 8) + (rr & 255) * n_ty;
+                yy = yt0 + (rr >> 8) + (rr & 255) * n_ty;
             }
-            const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tid;
+            const int tile_idx = tr * lv.ntw + grp * kt + tcol;
             tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] =
                 ((unsigned long long)(unsigned)sc << 32) | ((unsigned)(yy & 0xFFFF) << 16) | (unsigned)(xx & 0xFFFF);
         }
