@@ -283,6 +283,22 @@ void build_lut_bits(int nmin, int nmax, std::vector<uint32_t> &bits)
     }
 }
 
+// The device copy of the LUT is stored at the index k_detect forms: ring pixel k (bit k of the reference's mask) sits at bit
+// detect_ring_bit_of_pixel(k) of the index.
+void permute_lut_bits(const std::vector<uint32_t> &ref, uint32_t *out)
+{
+    int perm[16];
+    for (int k = 0; k < 16; k++) perm[k] = detect_ring_bit_of_pixel(k);
+    for (int w = 0; w < 2048; w++) out[w] = 0u;
+    for (int j = 0; j < 65536; j++)
+        if ((ref[j >> 5] >> (j & 31)) & 1u) {
+            unsigned ix = 0;
+            for (int k = 0; k < 16; k++)
+                if (j & (1 << k)) ix |= 1u << perm[k];
+            out[ix >> 5] |= 1u << (ix & 31);
+        }
+}
+
 int enqueue_timed(jsorb_extractor *e, int id)
 {
     if (!e->timing) return JSORB_OK;
@@ -596,6 +612,10 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
                 const int m0 = j & 1, m4 = (j >> 4) & 1, m8 = (j >> 8) & 1, m12 = (j >> 12) & 1;
                 if (!((m0 | m8) & (m4 | m12))) g.lut_compass = 0;
             }
+        {   // reference bit order -> the order k_detect indexes the table with
+            std::vector<uint32_t> ref(bits.begin(), bits.begin() + 2048);
+            permute_lut_bits(ref, bits.data());
+        }
         // workgroup tables (jsorb_device.h, CTAB_*): level | tile row << 4 | tile column << 18
         bits.resize(2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS, 0u);
         for (int i = 0; i < g.L; i++) {                    // column priorities of K3's horizontal tree (k_detect phase 3/4)

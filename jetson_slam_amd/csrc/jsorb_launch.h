@@ -22,6 +22,7 @@ size_t detect_lds_bytes(const Geometry &g);
 size_t pyramid_lds_bytes(const Geometry &g);
 size_t pyramid_window_bytes(float s, int rows_out);      // LDS bytes of the level-0 window of one k_pyramid tile
 void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, const uint32_t *ctab, int n_images, size_t lds_bytes, hipStream_t s);
+int detect_ring_bit_of_pixel(int k);       // bit of ring pixel k in the index of the arc LUT as k_detect forms it (the host stores the LUT in that order)
 void fill_detect_layout(Geometry &g);      // tile rows per workgroup (det_R), workgroup table offsets and per-level LDS layout of k_detect (host side, once per handle)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s);

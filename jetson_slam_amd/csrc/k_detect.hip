@@ -114,6 +114,17 @@ size_t detect_lds_bytes(const Geometry &g)
     return m;
 }
 
+// Bit order of the ring masks inside k_detect's phase 2 (see there): the 32-bit word has ring pixel 4j + b at bit 8b + 7 - j; squeezed
+// to 16 bits for the arc LUT, pixel 4j + b sits at bit 4b + 3 - j.  build_lut_bits() on the host stores the LUT in this order.
+__host__ __device__ __forceinline__ int ring_bit_of_pixel(int k) { return 4 * (k & 3) + 3 - (k >> 2); }
+__device__ __forceinline__ unsigned ring_word_to_index(unsigned w)
+{
+    const unsigned x = w >> 4;                 // nibbles at bits 0-3, 8-11, 16-19, 24-27
+    const unsigned y = x | (x >> 4);           // byte 0 = nibble0 | nibble1 << 4, byte 2 = nibble2 | nibble3 << 4
+    return (y & 0xFFu) | ((y >> 8) & 0xFF00u);
+}
+int detect_ring_bit_of_pixel(int k) { return ring_bit_of_pixel(k); }
+
 template <bool HAS_MASK, bool COMPASS>
 __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
@@ -235,32 +246,44 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
                     const int ry = e >> 8, rx = e & 255;
                     const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
                     const int v = c[0], vt = v + threshold, v_t = v - threshold;
-                    int p[16];
-                    p[0] = c[3 * S];       p[1] = c[3 * S + 1];   p[2] = c[2 * S + 2];   p[3] = c[S + 3];
-                    p[4] = c[3];           p[5] = c[-S + 3];      p[6] = c[-2 * S + 2];  p[7] = c[-3 * S + 1];
-                    p[8] = c[-3 * S];      p[9] = c[-3 * S - 1];  p[10] = c[-2 * S - 2]; p[11] = c[-S - 3];
-                    p[12] = c[-3];         p[13] = c[S - 3];      p[14] = c[2 * S - 2];  p[15] = c[3 * S - 1];
-                    // brighter / darker masks, bit k = ring pixel k.  Two VALU per bit and no SGPR round trip: the sign bit of
-                    // (vt - p) [p > vt] or (p - v_t) [p < v_t] is shifted into the mask with one v_alignbit_b32.
+                    // the 16 ring pixels as 8 packed pairs (pixel 2i in the low, 2i+1 in the high half of P[i]): every test below works
+                    // on two pixels per instruction (v_pk_sub_i16 / v_perm / v_sad_u16)
+                    unsigned P[8];
+                    P[0] = (unsigned)c[3 * S] | ((unsigned)c[3 * S + 1] << 16);
+                    P[1] = (unsigned)c[2 * S + 2] | ((unsigned)c[S + 3] << 16);
+                    P[2] = (unsigned)c[3] | ((unsigned)c[-S + 3] << 16);
+                    P[3] = (unsigned)c[-2 * S + 2] | ((unsigned)c[-3 * S + 1] << 16);
+                    P[4] = (unsigned)c[-3 * S] | ((unsigned)c[-3 * S - 1] << 16);
+                    P[5] = (unsigned)c[-2 * S - 2] | ((unsigned)c[-S - 3] << 16);
+                    P[6] = (unsigned)c[-3] | ((unsigned)c[S - 3] << 16);
+                    P[7] = (unsigned)c[2 * S - 2] | ((unsigned)c[3 * S - 1] << 16);
+                    // brighter / darker: sign bit of (vt - p) [p > vt] and of (p - v_t) [p < v_t] per 16-bit half; v_perm collects the sign
+                    // bytes of four pixels into one dword E_j, and the four E_j are merged with staggered shifts: pixel 4j + b ends up at
+                    // bit 8b + 7 - j.  The population count is taken from this word directly; the arc LUT is stored in the matching
+                    // bit order (build_lut_bits, ring_bit_of_pixel), so the rare lookup only squeezes the word to 16 bits.
+                    typedef short s2 __attribute__((ext_vector_type(2)));
+                    const s2 vt2 = __builtin_bit_cast(s2, (unsigned)vt * 0x10001u), v_t2 = __builtin_bit_cast(s2, ((unsigned)v_t & 0xFFFFu) * 0x10001u);
                     unsigned bright = 0, dark = 0;
 #pragma unroll
-                    for (int k = 15; k >= 0; k--) {
-                        bright = __builtin_amdgcn_alignbit(bright, (unsigned)(vt - p[k]), 31);
-                        dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p[k] - v_t), 31);
+                    for (int j = 0; j < 4; j++) {
+                        const s2 p0 = __builtin_bit_cast(s2, P[2 * j]), p1 = __builtin_bit_cast(s2, P[2 * j + 1]);
+                        const unsigned eb = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, (s2)(vt2 - p1)), __builtin_bit_cast(unsigned, (s2)(vt2 - p0)), 0x07050301u);
+                        const unsigned ed = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, (s2)(p1 - v_t2)), __builtin_bit_cast(unsigned, (s2)(p0 - v_t2)), 0x07050301u);
+                        bright |= (eb >> j) & (0x80808080u >> j);
+                        dark |= (ed >> j) & (0x80808080u >> j);
                     }
                     // arc LUT (8 KB bit table, global): a divergent dword gather costs the vector-memory pipeline ~1 lane/clk, so masks
                     // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
                     // of them is ever looked up, usually none)
                     unsigned lb = 0;
-                    if (__popc(bright) >= min_pop) lb = lut_bits[bright >> 5] >> (bright & 31);
-                    if (__popc(dark) >= min_pop) lb |= lut_bits[dark >> 5] >> (dark & 31);
+                    if (__popc(bright) >= min_pop) { const unsigned ix = ring_word_to_index(bright); lb = lut_bits[ix >> 5] >> (ix & 31); }
+                    if (__popc(dark) >= min_pop) { const unsigned ix = ring_word_to_index(dark); lb |= lut_bits[ix >> 5] >> (ix & 31); }
                     hit = (lb & 1u) != 0;
                     if (hit) {
-                        const unsigned v4 = (unsigned)v * 0x01010101u;
+                        const unsigned v2 = (unsigned)v * 0x10001u;
                         unsigned sad = 0;
 #pragma unroll
-                        for (int k = 0; k < 16; k += 4)
-                            sad = __builtin_amdgcn_sad_u8((unsigned)p[k] | ((unsigned)p[k + 1] << 8) | ((unsigned)p[k + 2] << 16) | ((unsigned)p[k + 3] << 24), v4, sad);
+                        for (int k = 0; k < 8; k++) sad = __builtin_amdgcn_sad_u16(P[k], v2, sad);
                         s_score[ry * L.score_w + rx] = (unsigned short)sad;
                     }
                 }
