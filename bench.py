@@ -416,9 +416,10 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_host_streamed(orb, torch, cfg, left_u, right_u, dev, P=128, seconds=1.5):
-    """north-star regime (i): images in pinned host memory, ONE hipMemcpyAsync per batch on the copy stream into a landing buffer that is
-    read in place as level 0 (double buffered, so the upload of batch k+1 overlaps the kernels of batch k), then the same kernels."""
+def measure_host_streamed(orb, torch, cfg, left_u, right_u, dev, P=256, seconds=1.5):
+    """north-star regime (i): images in pinned host memory, one hipMemcpyAsync per LANE of the batch on the copy stream into a landing
+    buffer that is read in place as level 0 (double buffered; a lane starts when its images have landed and its part of the buffer
+    is refilled when the lane that used it two batches ago has finished), then the same kernels."""
     H, W, L, tile, th, fx, bf = cfg
     n_u = left_u.shape[0]
     idx = np.arange(P) % n_u

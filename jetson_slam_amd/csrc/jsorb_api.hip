@@ -68,7 +68,8 @@ struct jsorb_extractor {
     // in place as level 0.  Double buffering lets the upload of batch k+1 overlap the kernels of batch k.
     uint8_t *stage[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2][JSORB_MAX_LANES] = {};   // per landing buffer and lane: the lane's images have arrived
+    int consumed_n[2] = {0, 0};        // images of the batch that last used the buffer (with consumed_K: its lane partition)
     hipEvent_t ev_consumed[2][JSORB_MAX_LANES] = {};   // per landing buffer and lane
     int consumed_K[2] = {0, 0};        // lanes whose ev_consumed must be waited for before the buffer is refilled (0: never used)
     int stage_cur = 0, last_stage = -1;
@@ -383,8 +384,8 @@ int plan_lanes(const jsorb_extractor *e, int n, int *first)
 //  * work the caller (or this handle) enqueued on the main stream: lanes >= 1 wait for a fork event recorded on lane 0
 //  * the previous batch of this handle, when its lane partition differs (same partition: same-stream order is enough)
 //  * a stereo match enqueued on ANOTHER handle's lanes that may still read this handle's previous results
-//  * `input_ready` (optional): e.g. the upload of this batch on the copy stream
-int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, const hipStream_t *ls, hipEvent_t input_ready)
+//  * `input_ready` (optional, one event per lane): e.g. the upload of the lane's images on the copy stream
+int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, const hipStream_t *ls, const hipEvent_t *input_ready)
 {
     if ((K > 1 || ls[0] != e->stream) && (e->stream != e->own_stream || e->main_stream_dirty)) {
         // a caller-provided main stream (or copies this call put on the main stream) may carry work the images depend on.  The
@@ -407,12 +408,12 @@ int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, const hipStream_
                 if ((aligned ? i == j : true) && e->readers_stream[i] != ls[j]) HIPCHK(e, hipStreamWaitEvent(ls[j], e->lane_readers_done[i], 0));
         e->has_readers = false;
     }
-    if (input_ready)
-        for (int j = 0; j < K; j++) HIPCHK(e, hipStreamWaitEvent(ls[j], input_ready, 0));
+    if (input_ready)            // per lane: e.g. the upload of this lane's images on the copy stream
+        for (int j = 0; j < K; j++) HIPCHK(e, hipStreamWaitEvent(ls[j], input_ready[j], 0));
     return JSORB_OK;
 }
 
-int run_pipeline(jsorb_extractor *e, int n, hipEvent_t input_ready = nullptr)
+int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = nullptr)
 {
     const Geometry &g = e->g;
     int first[JSORB_MAX_LANES + 1];
@@ -566,8 +567,10 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
         HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
             HIPCHK(e, hipMalloc(&e->stage[k], B * (size_t)g.lv[0].H * g.lv[0].W + 256));
-            HIPCHK(e, hipEventCreateWithFlags(&e->ev_copied[k], hipEventDisableTiming));
-            for (int j = 0; j < JSORB_MAX_LANES; j++) HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k][j], hipEventDisableTiming));
+            for (int j = 0; j < JSORB_MAX_LANES; j++) {
+                HIPCHK(e, hipEventCreateWithFlags(&e->ev_copied[k][j], hipEventDisableTiming));
+                HIPCHK(e, hipEventCreateWithFlags(&e->ev_consumed[k][j], hipEventDisableTiming));
+            }
         }
     }
     HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
@@ -693,9 +696,10 @@ void jsorb_destroy(jsorb_extractor *e)
             if (e->ev_stage[j][q]) (void)hipEventDestroy(e->ev_stage[j][q]);
     }
     for (int k = 0; k < 2; k++) {
-        if (e->ev_copied[k]) (void)hipEventDestroy(e->ev_copied[k]);
-        for (int j = 0; j < JSORB_MAX_LANES; j++)
+        for (int j = 0; j < JSORB_MAX_LANES; j++) {
+            if (e->ev_copied[k][j]) (void)hipEventDestroy(e->ev_copied[k][j]);
             if (e->ev_consumed[k][j]) (void)hipEventDestroy(e->ev_consumed[k][j]);
+        }
     }
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -770,6 +774,7 @@ static int mark_buffer_consumed(jsorb_extractor *e, int k)
 {
     for (int j = 0; j < e->K; j++) HIPCHK(e, hipEventRecord(e->ev_consumed[k][j], lane_stream(e, j)));
     e->consumed_K[k] = e->K;
+    e->consumed_n[k] = e->n_images;
     e->last_stage = k;
     return JSORB_OK;
 }
@@ -799,10 +804,20 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     if (e->stage[0] && step == l0.W && image_stride == img_bytes) {
         // dense batch: ONE pinned hipMemcpyAsync for all images on the copy stream, then level 0 is read in place from the landing
         // buffer.  The buffer being refilled was last read two batches ago (its extract kernels and, if any, the stereo match).
+        // The upload is cut at the lane boundaries of the batch: lane j starts as soon as ITS images have landed, and its part of the
+        // buffer is refilled as soon as lane j of the batch that used the buffer two batches ago (extract kernels and, if any, the
+        // stereo match) has finished - the copy engine never waits for a whole batch.
         const int k = e->stage_cur;
-        if ((rc = wait_buffer_consumed(e, k, e->copy_stream))) return rc;
-        HIPCHK(e, hipMemcpyAsync(e->stage[k], host_images, img_bytes * n_images, hipMemcpyHostToDevice, e->copy_stream));
-        HIPCHK(e, hipEventRecord(e->ev_copied[k], e->copy_stream));
+        int first[JSORB_MAX_LANES + 1];
+        const int K = plan_lanes(e, n_images, first);
+        const bool same_split = e->consumed_K[k] == K && e->consumed_n[k] == n_images;
+        if (!same_split && (rc = wait_buffer_consumed(e, k, e->copy_stream))) return rc;
+        for (int j = 0; j < K; j++) {
+            if (same_split) HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->ev_consumed[k][j], 0));
+            HIPCHK(e, hipMemcpyAsync(e->stage[k] + (size_t)first[j] * img_bytes, host_images + (size_t)first[j] * img_bytes,
+                                     img_bytes * (size_t)(first[j + 1] - first[j]), hipMemcpyHostToDevice, e->copy_stream));
+            HIPCHK(e, hipEventRecord(e->ev_copied[k][j], e->copy_stream));
+        }
         e->src.l0 = e->stage[k]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
         if ((rc = run_pipeline(e, n_images, e->ev_copied[k]))) return rc;
         e->stage_cur = k ^ 1;
