@@ -59,6 +59,11 @@ struct jsorb_extractor {
     int lane_first[JSORB_MAX_LANES + 1] = {};
     bool has_readers = false;
     int readers_K = 0, readers_n = 0;
+    // level 0 has to be copied into the pitched slab first (strided host input, device input with unaligned rows): done per lane, on
+    // the lane's stream, right before its kernels
+    const uint8_t *copy_src = nullptr;
+    size_t copy_stride = 0;
+    int copy_step = 0, copy_kind = 0;      // 0 none, 1 host (hipMemcpy2DAsync per image), 2 device (one copy kernel per lane)
     bool main_stream_dirty = false;    // this call enqueued input copies on the main stream: the lanes must fork after them
     bool counts_synced = false;        // h_counts / h_stats reflect the last enqueued batch (set by jsorb_sync)
     size_t detect_lds = 0, pyr_lds = 0;
@@ -441,6 +446,14 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         uint8_t *slab = e->slab + (size_t)f * g.slab_bytes, *blur = e->blur + (size_t)f * g.slab_bytes;
         unsigned long long *tile_out = e->tile_out + f * T, *kp = e->kp + f * T;
         int *counts = e->counts + f * CW;
+        if (e->copy_kind == 1) {
+            for (int i = f; i < f + m; i++)
+                HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * g.slab_bytes, g.lv[0].pitch, e->copy_src + (size_t)i * e->copy_stride, e->copy_step,
+                                           g.lv[0].W, g.lv[0].H, hipMemcpyHostToDevice, st));
+        } else if (e->copy_kind == 2) {
+            launch_copy_level0(e->copy_src + (size_t)f * e->copy_stride, e->copy_stride, e->copy_step, e->slab + (size_t)f * g.slab_bytes, g.slab_bytes,
+                               g.lv[0].pitch, g.lv[0].W, g.lv[0].H, m, st);
+        }
         // single image on an untimed handle: replay the captured graph of the five launches when nothing they depend on has changed
         bool capturing = false;
         if (direct && e->use_frame_graph && !e->timing && !e->nms_ms) {
@@ -491,6 +504,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         if (!direct) HIPCHK(e, hipMemcpyAsync(e->h_counts + f * CW, counts, sizeof(int) * CW * m, hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
     }
+    e->copy_kind = 0;
     e->mirror_pending = direct;
     e->deliver_kp_dev = nullptr;
     e->deliver_desc_dev = nullptr;
@@ -823,11 +837,8 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
         e->stage_cur = k ^ 1;
         return mark_buffer_consumed(e, k);
     }
-    if ((rc = join_previous_on_main(e))) return rc;
-    e->main_stream_dirty = true;
-    for (int i = 0; i < n_images; i++)   // strided input: one 2-D copy per image into the pitched slab (main stream; the lanes fork after it)
-        HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, host_images + (size_t)i * image_stride, step,
-                                   l0.W, l0.H, hipMemcpyHostToDevice, e->stream));
+    // strided input: one 2-D copy per image into the pitched slab, enqueued by run_pipeline on the stream of the lane that owns the image
+    e->copy_src = host_images; e->copy_stride = image_stride; e->copy_step = step; e->copy_kind = 1;
     e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
     e->last_stage = -1;
     return run_pipeline(e, n_images);
@@ -843,12 +854,8 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     if (in_place) {   // level 0 is read where it lies: no copy of the grayscale plane
         e->src.l0 = dev_images; e->src.l0_stride = image_stride; e->src.l0_pitch = step;
     } else {
-        const int rc = join_previous_on_main(e);
-        if (rc) return rc;
-        e->main_stream_dirty = true;
-        for (int i = 0; i < n_images; i++)
-            HIPCHK(e, hipMemcpy2DAsync(e->slab + (size_t)i * e->g.slab_bytes, l0.pitch, dev_images + (size_t)i * image_stride, step,
-                                       l0.W, l0.H, hipMemcpyDeviceToDevice, e->stream));
+        // rows that are not 16-byte aligned: one copy kernel per lane brings level 0 into the pitched slab (run_pipeline, lane stream)
+        e->copy_src = dev_images; e->copy_stride = image_stride; e->copy_step = step; e->copy_kind = 2;
         e->src.l0 = e->slab; e->src.l0_stride = e->g.slab_bytes; e->src.l0_pitch = l0.pitch;
     }
     e->last_stage = -1;
