@@ -70,6 +70,13 @@ void jsorb_destroy(jsorb_extractor *e);
 const char *jsorb_last_error(const jsorb_extractor *e);
 const char *jsorb_version(void);
 
+/* The mask image the reference loads with cv::imread(str_mask) + cvtColor(BGR2GRAY) (orb_gpu.cpp:64-75; yaml keys mask.left / mask.right):
+ * decodes a PNG (non-interlaced; gray, gray+alpha, RGB, RGBA, palette; 1-16 bit) or a binary PGM / PPM file to one gray byte per pixel, for
+ * callers that do not link OpenCV.  Call with gray_out = NULL to obtain the size first.  JSORB_ERR_STATE: the file cannot be opened (the
+ * reference then runs without a mask); JSORB_ERR_UNSUPPORTED: not one of these formats (text in jsorb_mask_image_last_error). */
+int jsorb_read_mask_image(const char *path, int *width, int *height, uint8_t *gray_out, size_t capacity);
+const char *jsorb_mask_image_last_error(void);
+
 /* ---- extraction ---- */
 /* Reference-shaped call: one host image (step = bytes per row), results stay on the device; *n_keypoints = N.  Synchronous. */
 int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints);

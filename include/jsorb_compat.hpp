@@ -13,7 +13,7 @@
 // plus three helpers that are the bodies of Frame.cpp:119-196 (UnpackFrame), :463-479 (AssignFeaturesToGrid) and a free-function form of
 // Frame::ComputeStereoMatches.  No HIP / CUDA / OpenCV header is needed by the consumer: all device work goes through the ABI.
 // Define JSORB_WITH_OPENCV before including to get the cv::Mat / cv::KeyPoint overloads (the exact reference signatures) and mask
-// loading through cv::imread; without it masks are read from binary PGM / PPM files.
+// loading through cv::imread; without it masks are decoded by libjsorb itself (PNG, binary PGM / PPM: jsorb_read_mask_image).
 #ifndef JSORB_COMPAT_HPP
 #define JSORB_COMPAT_HPP
 
@@ -157,40 +157,6 @@ inline void ORB_compute_distances(int n_points, int *idx_left, int *idx_right, u
         throw std::runtime_error("jsorb_hamming_pairs failed");
 }
 
-namespace detail {
-// Binary PGM (P5) / PPM (P6), maxval <= 255 -> gray plane.  For a colour file the conversion is cv::cvtColor(BGR2GRAY)'s 8-bit
-// fixed-point form (R*9798 + G*19235 + B*3735 + 2^14) >> 15; for a gray file it is the identity, as imread(IMREAD_COLOR) followed by
-// BGR2GRAY is (the weights sum to 2^15).
-inline bool read_pnm_gray(const std::string &path, int &w, int &h, std::vector<unsigned char> &gray)
-{
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    auto token = [&](int &v) {
-        int c = fgetc(f);
-        while (c == '#' || c == ' ' || c == '\n' || c == '\r' || c == '\t') {
-            if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
-            c = fgetc(f);
-        }
-        v = 0;
-        bool any = false;
-        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = fgetc(f); any = true; }
-        return any;
-    };
-    const int m0 = fgetc(f), m1 = fgetc(f);
-    int maxv = 0;
-    bool ok = m0 == 'P' && (m1 == '5' || m1 == '6') && token(w) && token(h) && token(maxv) && w > 0 && h > 0 && maxv > 0 && maxv <= 255;
-    if (ok) {
-        const int ch = m1 == '6' ? 3 : 1;
-        std::vector<unsigned char> raw((size_t)w * h * ch);
-        ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
-        gray.resize((size_t)w * h);
-        for (size_t i = 0; ok && i < gray.size(); i++)
-            gray[i] = ch == 1 ? raw[i] : (unsigned char)((raw[3 * i] * 9798 + raw[3 * i + 1] * 19235 + raw[3 * i + 2] * 3735 + (1 << 14)) >> 15);
-    }
-    fclose(f);
-    return ok;
-}
-} // namespace detail
 
 // orb_cuda::ORB_GPU (include/cuda/orb_gpu.hpp:22-250, src/cuda/orb_gpu.cpp): owns one jsorb handle.  Only the members the reference's
 // untouched host code reaches are recreated.
@@ -224,11 +190,14 @@ public:
                 have = true;
             }
 #else
-            have = detail::read_pnm_gray(str_mask, mw, mh, mask);
-            if (!have) {
-                FILE *probe = fopen(str_mask.c_str(), "rb");
-                if (probe) { fclose(probe); throw std::invalid_argument("jsorb: mask file is not a binary PGM/PPM (build with JSORB_WITH_OPENCV for other formats): " + str_mask); }
+            // without OpenCV: libjsorb's own decoder (PNG, binary PGM / PPM) with cvtColor(BGR2GRAY)'s 8-bit arithmetic
+            int rc = jsorb_read_mask_image(str_mask.c_str(), &mw, &mh, nullptr, 0);
+            if (rc == JSORB_OK) {
+                mask.resize((size_t)mw * mh);
+                rc = jsorb_read_mask_image(str_mask.c_str(), &mw, &mh, mask.data(), mask.size());
             }
+            if (rc == JSORB_OK) have = true;
+            else if (rc != JSORB_ERR_STATE) throw std::invalid_argument(std::string("jsorb: mask file: ") + jsorb_mask_image_last_error());
 #endif
             if (have) {
                 // the reference resizes whatever size the mask has to every level (level 0 included) with INTER_NN; the ABI takes the

@@ -34,7 +34,7 @@ EXPORTS = [
     "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
     "jsorb_mem_free_device", "jsorb_mem_stream_create", "jsorb_mem_stream_destroy", "jsorb_mem_stream_sync", "jsorb_mem_h2d", "jsorb_mem_d2h",
     "jsorb_mem_d2d", "jsorb_mem_h2d_async", "jsorb_mem_d2h_async", "jsorb_mem_d2d_async", "jsorb_mem_set_zero", "jsorb_mem_set_zero_async",
-    "jsorb_mem_last_error",
+    "jsorb_mem_last_error", "jsorb_read_mask_image", "jsorb_mask_image_last_error",
 ]
 
 
@@ -98,6 +98,8 @@ def load_library(path=None):
         "jsorb_level_image_device": (P, [P, I, I, I]),
         "jsorb_copy_level_image": (I, [P, I, I, I, P]),
         "jsorb_copy_level_mask": (I, [P, I, P]),
+        "jsorb_read_mask_image": (I, [C.c_char_p, C.POINTER(I), C.POINTER(I), P, C.c_size_t]),
+        "jsorb_mask_image_last_error": (C.c_char_p, []),
         "jsorb_copy_tile_candidates": (I, [P, I, P, P, P]),
         "jsorb_copy_angles": (I, [P, I, P]),
         "jsorb_stereo_match": (I, [P, P, F, F, I, I, P, P, C.POINTER(JsorbStereoStats)]),
@@ -126,6 +128,23 @@ def load_library(path=None):
     return lib
 
 
+def read_mask_image(path):
+    """cv::imread(path) + cvtColor(BGR2GRAY) of the reference's mask loading (orb_gpu.cpp:64-75) without OpenCV: PNG / binary PGM / PPM -> (H, W)
+    uint8.  Returns None when the file cannot be opened (the reference then runs without a mask); raises on an unsupported format."""
+    lib = load_library()
+    w, h = C.c_int(), C.c_int()
+    rc = lib.jsorb_read_mask_image(os.fsencode(path), C.byref(w), C.byref(h), None, 0)
+    if rc == -4:
+        return None
+    if rc != 0:
+        raise JsorbError("jsorb_read_mask_image rc=%d: %s" % (rc, lib.jsorb_mask_image_last_error().decode()))
+    out = np.zeros((h.value, w.value), np.uint8)
+    rc = lib.jsorb_read_mask_image(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data, out.size)
+    if rc != 0:
+        raise JsorbError("jsorb_read_mask_image rc=%d: %s" % (rc, lib.jsorb_mask_image_last_error().decode()))
+    return out
+
+
 class ORBExtractor:
     """Mirror of Jetson_SLAM::ORBExtractor (include/ORBextractor.h:21-93) over the C ABI.
 
@@ -139,7 +158,14 @@ class ORBExtractor:
         self._lib = load_library()
         self._h = C.c_void_p()
         mask = None
-        if str_mask is not None and not isinstance(str_mask, str):
+        if isinstance(str_mask, str) and str_mask:
+            mask = read_mask_image(str_mask)                  # the reference's image path (None = unreadable = no mask, orb_gpu.cpp:69-73)
+            if mask is not None and mask.shape != (im_height, im_width):
+                # the reference resizes whatever size the mask has to every level with INTER_NN: bring it to level-0 size with the same index rule
+                sy = np.minimum(np.floor(np.arange(im_height) * (1.0 / (im_height / float(mask.shape[0])))).astype(np.int64), mask.shape[0] - 1)
+                sx = np.minimum(np.floor(np.arange(im_width) * (1.0 / (im_width / float(mask.shape[1])))).astype(np.int64), mask.shape[1] - 1)
+                mask = np.ascontiguousarray(mask[sy][:, sx])
+        elif str_mask is not None and not isinstance(str_mask, str):
             mask = np.ascontiguousarray(str_mask, np.uint8)   # an (H, W) array instead of the reference's image path
             assert mask.shape == (im_height, im_width)
         self.params = JsorbParams(im_height, im_width, n_levels, scale_factor, FAST_N_MIN, FAST_N_MAX, th_FAST_MIN,
