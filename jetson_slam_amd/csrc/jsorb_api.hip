@@ -690,6 +690,8 @@ void jsorb_destroy(jsorb_extractor *e)
                 e->th_st_n ? e->th_st_wait / e->th_st_n : 0.0);
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    if (e->has_readers)       // a stereo match enqueued through another handle may still be reading this handle's buffers
+        for (int j = 0; j < e->readers_K; j++) (void)hipEventSynchronize(e->lane_readers_done[j]);
     if (e->frame_graph) (void)hipGraphExecDestroy(e->frame_graph);
     for (int j = 0; j < e->K; j++)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
