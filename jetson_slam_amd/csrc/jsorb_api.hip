@@ -435,8 +435,9 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
     if ((rc = order_lanes_for_new_batch(e, K, n, ls, input_ready))) return rc;
     const size_t T = (size_t)g.T;
     const int CW = JSORB_MAX_LEVELS + 1;
-    // a single image: k_compact / k_describe write counts, keypoints and descriptors straight into the pinned host mirrors (and into
-    // the caller's device buffers, jsorb_extract_into) - no copies behind the kernels
+    // k_compact writes the counts of every image straight into the pinned host mirror (no copy behind the kernels, for batches as
+    // well); for a single image k_describe also delivers keypoints and descriptors there and into the caller's device buffers
+    // (jsorb_extract_into)
     const bool direct = n == 1;
     for (int j = 0; j < K; j++) {
         const int f = first[j], m = first[j + 1] - f;
@@ -486,7 +487,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         if (e->nms_ms)
             JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
                                                       e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
-        JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st, direct ? e->h_counts : nullptr));
+        JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_len, m, st, e->h_counts + f * CW));
         JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
         JSORB_STAGE(JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st,
                                                       direct ? Deliver{e->deliver_kp_dev, e->deliver_desc_dev, e->h_kp, e->h_desc, nullptr}
@@ -501,7 +502,6 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
             HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
         }
         HIPCHK(e, hipGetLastError());
-        if (!direct) HIPCHK(e, hipMemcpyAsync(e->h_counts + f * CW, counts, sizeof(int) * CW * m, hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
     }
     e->copy_kind = 0;
@@ -1099,9 +1099,8 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_len,
                                               l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st));
         TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
-                                              l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, nullptr}));
+                                              l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, l->h_stats + f * 8}));
         HIPCHK(l, hipGetLastError());
-        if (!direct) HIPCHK(l, hipMemcpyAsync(l->h_stats + f * 8, l->st_stats + f * 8, sizeof(int) * 8 * m, hipMemcpyDeviceToHost, st));
         HIPCHK(l, hipEventRecord(l->lane_done[j], st));
         if (r != l) { HIPCHK(l, hipEventRecord(r->lane_readers_done[j], st)); r->readers_stream[j] = st; }
         // the L1 refinement reads both level-0 planes in place: a landing buffer is free for the next upload only after this point

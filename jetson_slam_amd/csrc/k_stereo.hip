@@ -346,7 +346,7 @@ __device__ __noinline__ void median_big(const Geometry &g, const int *__restrict
     __syncthreads();
     if (tid == 0) {
         const int v[4] = {s_cand, s_corr, nv, nv - s_removed};
-        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[k] = v[k]; }
+        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[b * 8 + k] = v[k]; }
     }
 }
 
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
     if (tid == 0) {
         const int v[4] = {s_cand, s_corr, nv, nv - s_removed};
 #pragma unroll
-        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[k] = v[k]; }
+        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[b * 8 + k] = v[k]; }
     }
 }
 
