@@ -42,9 +42,31 @@ __constant__ unsigned c_gauss_bits[7][4] = {
 #define BLUR_STRIDE (BLUR_TW + 16)
 #define BLUR_HALF (BLUR_STRIP / 2)
 
+// ---- certified fast path -------------------------------------------------------------------------------------------------
+// The reference's value is C = trunc(chain), the chain being 49 sequentially rounded FMAs.  The weights are (up to float rounding)
+// an outer product w[j][k] ~ gv[j] * gh[k], so the same real-valued sum S can be approximated by a separable evaluation A
+// (7 vertical + 7 horizontal FMAs per pixel instead of 49).  Both C and A are within rigorous bounds of S:
+//   |C - S| <= gamma_49 * 255 * sum(w)                          = 7.45e-4      (gamma_n = n u / (1 - n u), u = 2^-24)
+//   |A - S| <= rounding of the two 7-FMA stages + 255 * sum |gv[j] gh[k] - w[j][k]|  = 2.13e-4 + 0.9e-5
+// (tests/test_blur_certificate.py recomputes both from the tables with exact rational arithmetic), hence |A - C| <= 9.7e-4.
+// A pixel whose A is farther than BLUR_DELTA = 2e-3 from an integer boundary therefore has floor(C) = floor(A) - decided with two
+// magic-number roundings; the others (~0.4 % of natural pixels; every pixel of an exactly flat window, whose C lies within 1e-4 of an
+// integer) are listed per workgroup and recomputed with the exact chain; a tile with too many of them is recomputed densely by the
+// exact strip code.  The output is bit-identical to the chain in every case.
+#define BLUR_DELTA 2.0e-3f
+#define BLUR_AMB_CAP 1024      // listed ambiguous pixels per workgroup (of 8192) before the dense exact path takes over
+
+// separable factors: gv[j] = exp(-j^2/200) and gh[k] = exp(-k^2/200) / 47.092777252197266 (the reference's f32 weight sum 0x423C5F01),
+// rounded to f32 from double; sum |gv[j] gh[k] - w[j][k]| = 3.4e-8 for these
+__constant__ float c_sep_v[4] = {1.0f, 0.99501247919268232f, 0.98019867330675525f, 0.95599748183309996f};
+__constant__ float c_sep_h[4] = {(float)(1.0 / 47.092777252197266), (float)(0.99501247919268232 / 47.092777252197266),
+                                 (float)(0.98019867330675525 / 47.092777252197266), (float)(0.95599748183309996 / 47.092777252197266)};
+
 __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *__restrict__ ctab, int n_images)
 {
     __shared__ __align__(16) unsigned char tile[(BLUR_TH + 6) * BLUR_STRIDE];
+    __shared__ unsigned short s_amb[BLUR_AMB_CAP];
+    __shared__ int s_namb;
     const int tid = threadIdx.x;
     // workgroup-independent arguments in the first round of scalar loads, the workgroup descriptor (level, tile) in the second,
     // the level in the third: the first image byte cannot be requested earlier (see k_detect)
@@ -69,30 +91,20 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
         if (y < H && x + 16 <= pitch) v = *reinterpret_cast<const uint4 *>(img + (size_t)y * pitch + x);
         reinterpret_cast<uint4 *>(tile)[i] = v;
     }
+    if (tid == 0) s_namb = 0;
     __syncthreads();
 
     constexpr int SPR = BLUR_TW / BLUR_STRIP;         // strips per tile row
     const int ty = tid / SPR, tx = tid % SPR;
     const int y = y0 + BLUR_ROWS * ty, x = x0 + BLUR_STRIP * tx;
-    if (y >= H - JSORB_BORDER || x >= W - JSORB_BORDER) return;
+    const bool active = y < H - JSORB_BORDER && x < W - JSORB_BORDER;      // no early return: two more workgroup barriers follow
+    const int n_valid = (W - JSORB_BORDER) - x;      // pixels of the strip inside the ROI
+    uint8_t *const out_base = blur_slab + (size_t)b * g.slab_bytes + lv.img_off;
 
-    // BLUR_STRIP independent FMA chains per output row, evaluated two at a time with v_pk_fma_f32 (IEEE fma per component, so each
-    // chain is still the reference's 49 sequential single-rounding FMAs).  A[o][j] = (acc of pixel j, acc of pixel j + HALF): for
-    // tap column c its operand pair is Q[1+j+c] = (f[1+j+c], f[1+j+c+HALF]) - pairs HALF bytes apart need no re-alignment moves.
-    // The kernel is vector-ALU bound and the u8 -> f32 conversions are ~40 % of it, so a thread owns a wide strip (fewer halo
-    // conversions) of BLUR_ROWS adjacent rows (each converted input row feeds both output rows).
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 A[BLUR_ROWS][BLUR_HALF];
-#pragma unroll
-    for (int o = 0; o < BLUR_ROWS; o++)
-#pragma unroll
-        for (int j = 0; j < BLUR_HALF; j++) A[o][j] = (f2){0.0f, 0.0f};
-    // The row loop is NOT fully unrolled: unrolled, the compiler's schedule needs 140-200 VGPRs (2-3 waves per SIMD), and this
-    // kernel needs the occupancy to overlap the staging phase of one workgroup with the arithmetic of the others.  The weights
-    // of tap row r come from a constant table through scalar loads.  Input rows 0 and 7 feed one output row each and are peeled;
-    // rows 1..6 feed both and run as 3 iterations of two rows with two ping-pong row buffers (no register copies, no branches).
-    static_assert(BLUR_ROWS == 2, "the row schedule below is written for two output rows per thread");
+    static_assert(BLUR_ROWS == 2 && BLUR_STRIP == 16, "the schedules below are written for 16 px x 2 rows per thread");
     constexpr int NW = BLUR_STRIP / 4 + 2;
+    constexpr int NP = BLUR_HALF + 6;                 // 14 operand pairs (f[k], f[k + 8]), k = 1 .. 14: window columns of the 16 pixels
     const unsigned char *rowp = tile + (BLUR_ROWS * ty) * BLUR_STRIDE + BLUR_STRIP * tx;
     auto load_row = [&](unsigned (&w)[NW], int row) {
 #pragma unroll
@@ -105,6 +117,148 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
             Q[k] = (f2){(float)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu), (float)((w[k2 >> 2] >> (8 * (k2 & 3))) & 0xFFu)};
         }
     };
+    auto store_rows = [&](const unsigned (&ow)[BLUR_ROWS][BLUR_STRIP / 4]) {
+#pragma unroll
+        for (int o = 0; o < BLUR_ROWS; o++) {
+            if (y + o >= H - JSORB_BORDER) break;
+            uint8_t *dst = out_base + (size_t)(y + o) * lv.pitch + x;
+            if (n_valid >= BLUR_STRIP) {
+#pragma unroll
+                for (int k = 0; k < BLUR_STRIP / 4; k++) reinterpret_cast<unsigned *>(dst)[k] = ow[o][k];
+            } else {
+#pragma unroll
+                for (int j = 0; j < BLUR_STRIP; j++)
+                    if (j < n_valid) dst[j] = (uint8_t)((ow[o][j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            }
+        }
+    };
+
+    // ---- fast pass: separable evaluation + certificate ----
+    if (active) {
+        f2 VA[BLUR_ROWS][NP];
+#pragma unroll
+        for (int o = 0; o < BLUR_ROWS; o++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) VA[o][k] = (f2){0.0f, 0.0f};
+        unsigned wa[NW];
+        f2 Q[BLUR_HALF + 7];
+        // vertical stage: input row r feeds tap row r of output row 0 (r <= 6) and tap row r - 1 of output row 1 (r >= 1); rows 0 and 7
+        // feed one output row each and are peeled, rows 1 .. 6 run as a rolled loop (weights through scalar loads)
+        load_row(wa, 0);
+        convert(wa, Q);
+        {
+            const f2 g02 = (f2){c_sep_v[3], c_sep_v[3]};
+#pragma unroll
+            for (int k = 0; k < NP; k++) VA[0][k] = g02 * Q[1 + k];
+        }
+#pragma unroll 1
+        for (int r = 1; r < 7; r++) {
+            load_row(wa, r);
+            convert(wa, Q);
+            const int t0 = r < 4 ? 3 - r : r - 3, t1 = r < 5 ? 4 - r : r - 4;      // |tap row - 3| (wave-uniform)
+            const float g0 = c_sep_v[t0], g1 = c_sep_v[t1];
+            const f2 g02 = (f2){g0, g0}, g12 = (f2){g1, g1};
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                VA[0][k] = __builtin_elementwise_fma(g02, Q[1 + k], VA[0][k]);
+                VA[1][k] = __builtin_elementwise_fma(g12, Q[1 + k], VA[1][k]);
+            }
+        }
+        load_row(wa, 7);
+        convert(wa, Q);
+        {
+            const f2 g12 = (f2){c_sep_v[3], c_sep_v[3]};
+#pragma unroll
+            for (int k = 0; k < NP; k++) VA[1][k] = __builtin_elementwise_fma(g12, Q[1 + k], VA[1][k]);
+        }
+        // horizontal stage + certificate, pixel pair (j, j + 8) at a time
+        const f2 gh2[4] = {(f2){c_sep_h[0], c_sep_h[0]}, (f2){c_sep_h[1], c_sep_h[1]}, (f2){c_sep_h[2], c_sep_h[2]}, (f2){c_sep_h[3], c_sep_h[3]}};
+        const f2 zlo = (f2){-0.5f - BLUR_DELTA, -0.5f - BLUR_DELTA}, zhi = (f2){-0.5f + BLUR_DELTA, -0.5f + BLUR_DELTA};
+        const f2 magic = (f2){12582912.0f, 12582912.0f};
+        unsigned ow[BLUR_ROWS][BLUR_STRIP / 4];
+        unsigned amb = 0;                              // bit 16 o + p: pixel p of output row o needs the exact chain
+#pragma unroll
+        for (int o = 0; o < BLUR_ROWS; o++) {
+#pragma unroll
+            for (int jg = 0; jg < BLUR_HALF; jg += 4) {
+                unsigned lo4[4], hi4[4];               // rounded values of pixels jg .. jg+3 and jg+8 .. jg+11 (low byte = the result)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int j = jg + q;
+                    f2 h = gh2[3] * VA[o][j];
+                    h = __builtin_elementwise_fma(gh2[2], VA[o][j + 1], h);
+                    h = __builtin_elementwise_fma(gh2[1], VA[o][j + 2], h);
+                    h = __builtin_elementwise_fma(gh2[0], VA[o][j + 3], h);
+                    h = __builtin_elementwise_fma(gh2[1], VA[o][j + 4], h);
+                    h = __builtin_elementwise_fma(gh2[2], VA[o][j + 5], h);
+                    h = __builtin_elementwise_fma(gh2[3], VA[o][j + 6], h);
+                    // r1 = round(max(A - delta, 0) - 0.5), r2 = round(A + delta - 0.5): equal => floor(C) = r1 (see above); r2 - r1 is 0 or 1
+                    f2 z1 = h + zlo;
+                    const f2 z2 = h + zhi;
+                    z1.x = __builtin_fmaxf(z1.x, -0.5f);
+                    z1.y = __builtin_fmaxf(z1.y, -0.5f);
+                    const f2 r1 = z1 + magic, r2 = z2 + magic;
+                    lo4[q] = __float_as_uint(r1.x);
+                    hi4[q] = __float_as_uint(r1.y);
+                    amb = ((__float_as_uint(r2.x) - lo4[q]) << (16 * o + j)) | amb;
+                    amb = ((__float_as_uint(r2.y) - hi4[q]) << (16 * o + j + BLUR_HALF)) | amb;
+                }
+                // four low bytes -> one dword with three v_perm / v_or (the upper bytes of the rounded words hold the magic number)
+                ow[o][jg >> 2] = __builtin_amdgcn_perm(lo4[1], lo4[0], 0x0c0c0400u) | __builtin_amdgcn_perm(lo4[3], lo4[2], 0x04000c0cu);
+                ow[o][(jg + BLUR_HALF) >> 2] = __builtin_amdgcn_perm(hi4[1], hi4[0], 0x0c0c0400u) | __builtin_amdgcn_perm(hi4[3], hi4[2], 0x04000c0cu);
+            }
+        }
+        store_rows(ow);
+        // list the pixels that need the exact chain (inside the ROI only)
+        while (amb) {
+            const int pos = __builtin_ctz(amb);
+            amb &= amb - 1;
+            const int o = pos >> 4, p = pos & 15;
+            if (p < n_valid && y + o < H - JSORB_BORDER) {
+                const int idx = atomicAdd(&s_namb, 1);
+                if (idx < BLUR_AMB_CAP) s_amb[idx] = (unsigned short)((BLUR_ROWS * ty + o) * BLUR_TW + BLUR_STRIP * tx + p);
+            }
+        }
+    }
+    __syncthreads();      // also orders the dword stores above before the byte stores below (same addresses, other threads)
+    const int n_amb = s_namb;
+    if (n_amb == 0) return;
+    if (n_amb <= BLUR_AMB_CAP) {
+        // ---- exact chain for the listed pixels, one per lane: acc = fma(w[r][c], I, acc) in raster order ----
+        for (int i = tid; i < n_amb; i += 256) {
+            const int id = s_amb[i], ly = id / BLUR_TW, lx = id - ly * BLUR_TW;
+            const unsigned char *wp = tile + ly * BLUR_STRIDE + lx + 1;      // window row 0, column 0 (tile column 0 is x0 - 4)
+            float acc = 0.0f;
+#pragma unroll 1
+            for (int r = 0; r < 7; r++) {
+                const float w0 = c_gauss[r][0], w1 = c_gauss[r][1], w2 = c_gauss[r][2], w3 = c_gauss[r][3];
+                const unsigned char *q = wp + r * BLUR_STRIDE;
+                acc = __builtin_fmaf(w3, (float)q[0], acc);
+                acc = __builtin_fmaf(w2, (float)q[1], acc);
+                acc = __builtin_fmaf(w1, (float)q[2], acc);
+                acc = __builtin_fmaf(w0, (float)q[3], acc);
+                acc = __builtin_fmaf(w1, (float)q[4], acc);
+                acc = __builtin_fmaf(w2, (float)q[5], acc);
+                acc = __builtin_fmaf(w3, (float)q[6], acc);
+            }
+            out_base[(size_t)(y0 + ly) * lv.pitch + x0 + lx] = (uint8_t)((unsigned)acc & 0xFFu);
+        }
+        return;
+    }
+    if (!active) return;
+
+    // ---- dense exact path (a tile of mostly flat windows): the 49-FMA chains of the whole strip, two at a time ----
+    // BLUR_STRIP independent FMA chains per output row, evaluated two at a time with v_pk_fma_f32 (IEEE fma per component, so each
+    // chain is still the reference's 49 sequential single-rounding FMAs).  A[o][j] = (acc of pixel j, acc of pixel j + HALF): for
+    // tap column c its operand pair is Q[1+j+c] = (f[1+j+c], f[1+j+c+HALF]) - pairs HALF bytes apart need no re-alignment moves.
+    f2 A[BLUR_ROWS][BLUR_HALF];
+#pragma unroll
+    for (int o = 0; o < BLUR_ROWS; o++)
+#pragma unroll
+        for (int j = 0; j < BLUR_HALF; j++) A[o][j] = (f2){0.0f, 0.0f};
+    // The row loop is NOT fully unrolled: unrolled, the compiler's schedule needs 140-200 VGPRs.  The weights of tap row r come from a
+    // constant table through scalar loads.  Input rows 0 and 7 feed one output row each and are peeled; rows 1..6 feed both and run
+    // as 3 iterations of two rows with two ping-pong row buffers (no register copies, no branches).
     auto accum = [&](f2 (&acc)[BLUR_HALF], const f2 (&Q)[BLUR_HALF + 7], int r) {      // r: tap row (wave-uniform)
         const float wr[4] = {c_gauss[r][0], c_gauss[r][1], c_gauss[r][2], c_gauss[r][3]};
 #pragma unroll
@@ -129,28 +283,18 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
         load_row(wa, i + 3 < 8 ? i + 3 : 7);           // rows 4, 6 (the last load is unused)
     }
     convert(wb, Q); accum(A[1], Q, 6);                 // input row 7: tap row 6 of output row 1
-    const int n_valid = (W - JSORB_BORDER) - x;      // pixels of the strip inside the ROI
+    unsigned ow[BLUR_ROWS][BLUR_STRIP / 4];
 #pragma unroll
     for (int o = 0; o < BLUR_ROWS; o++) {
-        if (y + o >= H - JSORB_BORDER) break;
-        unsigned ow[BLUR_STRIP / 4];
 #pragma unroll
-        for (int k = 0; k < BLUR_STRIP / 4; k++) ow[k] = 0;
+        for (int k = 0; k < BLUR_STRIP / 4; k++) ow[o][k] = 0;
 #pragma unroll
         for (int j = 0; j < BLUR_HALF; j++) {
-            ow[j >> 2] |= ((unsigned)A[o][j].x & 0xFFu) << (8 * (j & 3));
-            ow[(j + BLUR_HALF) >> 2] |= ((unsigned)A[o][j].y & 0xFFu) << (8 * ((j + BLUR_HALF) & 3));
-        }
-        uint8_t *dst = blur_slab + (size_t)b * g.slab_bytes + lv.img_off + (size_t)(y + o) * lv.pitch + x;
-        if (n_valid >= BLUR_STRIP) {
-#pragma unroll
-            for (int k = 0; k < BLUR_STRIP / 4; k++) reinterpret_cast<unsigned *>(dst)[k] = ow[k];
-        } else {
-#pragma unroll
-            for (int j = 0; j < BLUR_STRIP; j++)
-                if (j < n_valid) dst[j] = (uint8_t)((ow[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            ow[o][j >> 2] |= ((unsigned)A[o][j].x & 0xFFu) << (8 * (j & 3));
+            ow[o][(j + BLUR_HALF) >> 2] |= ((unsigned)A[o][j].y & 0xFFu) << (8 * ((j + BLUR_HALF) & 3));
         }
     }
+    store_rows(ow);
 }
 
 void blur_tile_dims(int *tw, int *th) { *tw = BLUR_TW; *th = BLUR_TH; }

@@ -1,0 +1,87 @@
+"""k_blur's certified fast path (jetson_slam_amd/csrc/k_blur.hip): a separable 7+7-FMA evaluation A of the 7x7 blur decides floor(C) of the
+reference's 49-FMA chain C whenever A is farther than BLUR_DELTA from an integer boundary; the other pixels are recomputed exactly.  This
+test re-derives the rigorous bound |A - C| <= bound from the constants IN THE KERNEL SOURCE with exact rational arithmetic and requires
+BLUR_DELTA to cover it (plus the rounding of the test arithmetic itself) with margin, and checks the claim empirically on adversarial
+windows (the bit-exact -m gpu plane comparisons are what finally guard the kernel)."""
+import os
+import re
+from fractions import Fraction
+
+import numpy as np
+
+from oracle import host_restatement as hr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+U = Fraction(1, 2 ** 24)
+
+
+def _kernel_constants():
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur.hip")).read()
+    delta = float(re.search(r"#define BLUR_DELTA ([0-9.e+-]+)f", src).group(1))
+    body = src[src.index("__constant__ float c_sep_v[4]"):]
+    v = [float(t) for t in re.findall(r"([0-9.]+)f", body[:body.index(";")])]
+    hb = body[body.index("c_sep_h[4]"):]
+    hb = hb[:hb.index(";")]
+    h = [eval(t, {"__builtins__": {}}, {}) for t in re.findall(r"\(float\)\(([^)]*)\)", hb)]
+    return delta, np.array(v, np.float32), np.array(h, np.float32)
+
+
+def _gamma(n):
+    return n * U / (1 - n * U)
+
+
+def test_delta_covers_the_rigorous_error_bound():
+    delta, v4, h4 = _kernel_constants()
+    w = hr.CtorTables._gauss().reshape(7, 7)                              # the reference's f32 weights (glibc expf, f32 normalisation)
+    gv = [Fraction(float(v4[abs(j)])) for j in range(-3, 4)]
+    gh = [Fraction(float(h4[abs(k)])) for k in range(-3, 4)]
+    wq = [[Fraction(float(w[j, k])) for k in range(7)] for j in range(7)]
+    sum_w = sum(sum(r) for r in wq)
+    # chain of 49 FMAs: every term passes through at most 49 roundings
+    bound_c = _gamma(49) * 255 * sum_w
+    # separable: 7-FMA vertical stage on values <= 255 * sum(gv), then 7-FMA horizontal stage on its results
+    vmax = 255 * sum(gv)
+    bound_v = _gamma(7) * vmax
+    bound_a = _gamma(7) * sum(gh) * (vmax + bound_v) + sum(gh) * bound_v
+    model = 255 * sum(abs(gv[j] * gh[k] - wq[j][k]) for j in range(7) for k in range(7))
+    test_rounding = 2 * U * 512                                           # H + (-0.5 -+ delta) is rounded once more (|value| < 512)
+    total = bound_c + bound_a + model + test_rounding
+    assert float(total) < 1.05e-3, float(total)
+    assert delta >= 1.5 * float(total)                                    # 50 % margin on a bound that is itself worst-case
+    assert delta < 0.01                                                   # ... without listing more than ~2 % of natural pixels
+
+
+def test_certificate_decides_correctly_on_adversarial_windows():
+    delta, v4, h4 = _kernel_constants()
+    w = hr.CtorTables._gauss().reshape(7, 7)
+    gv = np.array([v4[abs(j)] for j in range(-3, 4)], np.float32)
+    gh = np.array([h4[abs(k)] for k in range(-3, 4)], np.float32)
+    rng = np.random.default_rng(11)
+    n = 200000
+    wins = [rng.integers(0, 256, (n, 7, 7), dtype=np.uint8),
+            np.repeat(np.arange(256, dtype=np.uint8), 8).reshape(-1, 1, 1).repeat(7, 1).repeat(7, 2),        # exactly flat windows: C within 1e-4 of an integer
+            rng.integers(250, 256, (n, 7, 7)).astype(np.uint8),
+            np.clip(rng.integers(0, 256, (n, 1, 1)) + rng.integers(-1, 2, (n, 7, 7)), 0, 255).astype(np.uint8),
+            np.zeros((16, 7, 7), np.uint8)]
+    decided = 0
+    for P in wins:
+        acc = np.zeros(P.shape[0], np.float32)
+        for j in range(7):
+            for k in range(7):                                            # f32 fma via f64 (exact product, one extra rounding far below the margins)
+                acc = (np.float64(w[j, k]) * P[:, j, k] + acc.astype(np.float64)).astype(np.float32)
+        V = np.zeros((P.shape[0], 7), np.float32)
+        for j in range(7):
+            V = (np.float64(gv[j]) * P[:, j, :] + V.astype(np.float64)).astype(np.float32)
+        A = np.zeros(P.shape[0], np.float32)
+        for k in (0, 1, 2, 3, 4, 5, 6):
+            A = (np.float64(gh[k]) * V[:, k] + A.astype(np.float64)).astype(np.float32)
+        assert np.abs(A.astype(np.float64) - acc.astype(np.float64)).max() < 0.5 * delta
+        z1 = np.maximum((A + np.float32(-0.5 - delta)).astype(np.float32), np.float32(-0.5))
+        z2 = (A + np.float32(-0.5 + delta)).astype(np.float32)
+        r1 = ((z1 + np.float32(12582912.0)).astype(np.float32).view(np.int32) - 0x4B400000)
+        r2 = ((z2 + np.float32(12582912.0)).astype(np.float32).view(np.int32) - 0x4B400000)
+        assert np.all((r2 - r1 == 0) | (r2 - r1 == 1))
+        sure = r1 == r2
+        assert np.array_equal(r1[sure], np.floor(acc[sure]).astype(np.int32))          # the certificate never lies
+        decided += int(sure.sum())
+    assert decided > 0.95 * 3 * n                                         # and it decides almost every natural pixel
