@@ -466,7 +466,12 @@ def measure_frame_latency(cfg, left, right, frames=300):
             out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=env,
                                  capture_output=True, text=True, timeout=120)
             res = json.loads(out.stdout.strip().splitlines()[-1])
-            res["what"] = "C++ driver shaped like Frame::Frame: extract L||R in two std::threads + 4 x SyncedMem::to_cpu + ComputeStereoMatches, host images in pageable memory"
+            res["what"] = ("C++ driver shaped like Frame::Frame: extract L||R in two std::threads + 4 x SyncedMem::to_cpu + ComputeStereoMatches, host images in "
+                           "pageable memory; the match of frame k is enqueued by the library behind the extracts of frame k (jsorb_set_speculative_stereo) and "
+                           "adopted by ComputeStereoMatches - total_us_plain is the same driver with JSORB_SPECULATE=0")
+            out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=dict(env, JSORB_SPECULATE="0"),
+                                 capture_output=True, text=True, timeout=120)
+            res["total_us_plain"] = json.loads(out.stdout.strip().splitlines()[-1])["total_us"]
             return res
         except Exception as e:      # never let a side measurement break the contract line
             return {"error": str(e)[:200]}

@@ -127,6 +127,15 @@ int jsorb_copy_angles(const jsorb_extractor *e, int image, float *host_dst);
  * ORBmatcher::TH_HIGH/TH_LOW = 100/50 (ORBmatcher.cpp:24-25). */
 int jsorb_stereo_match(jsorb_extractor *left, jsorb_extractor *right, float mb, float mbf, int th_high, int th_low,
                        float *u_right, float *depth, jsorb_stereo_stats *stats);
+/* Speculative match (on by default, JSORB_SPECULATE=0 or the call below turn it off).  After one jsorb_stereo_match on a (left, right)
+ * pair of single-image handles, the library enqueues the same match, with the same mb / mbf / thresholds, right behind the NEXT pair of
+ * single-image extracts on the GPU (the extract call that arrives second does it), so that the following jsorb_stereo_match on that
+ * pair finds its result finished instead of paying a host round trip between extract and match.  The result is adopted only when the
+ * call names the same pair and parameters and neither handle has extracted again; otherwise it is dropped and the call runs as if
+ * the feature did not exist.  Same kernels, same inputs, same outputs.  The two extract calls may come from two threads (as in
+ * Frame.cpp:107-110); calls on ONE handle must not overlap, as before. */
+int jsorb_set_speculative_stereo(jsorb_extractor *left, int on);
+int jsorb_speculative_stereo_stats(const jsorb_extractor *left, long *n_adopted, long *n_dropped);
 /* Batch mode: image i of `left` against image i of `right`; enqueues on left's stream after right's work. */
 int jsorb_stereo_match_batch_async(jsorb_extractor *left, jsorb_extractor *right, float mb, float mbf, int th_high, int th_low);
 const float *jsorb_stereo_uright_device(const jsorb_extractor *left, int image);

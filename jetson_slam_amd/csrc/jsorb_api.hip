@@ -34,6 +34,30 @@ struct TimedLaunch { int id; hipEvent_t a, b; };
 
 } // namespace
 
+// Stereo match enqueued AHEAD of the call that asks for it (the synchronous single-frame call shape, Frame.cpp:107-125: extract L and R
+// from two threads, join, ComputeStereoMatches).  Between the end of the two extracts on the GPU and the start of the match there is
+// a host round trip (wake-up of two waits, thread joins, the next call's launch) during which the GPU idles: 53 of the 182 us GPU
+// span of a frame.  Once a (left, right) pair has been matched through jsorb_stereo_match, the library repeats that match with the
+// same parameters right behind the NEXT pair of single-image extracts, on the GPU, without a host round trip: whichever of the two
+// extract calls enqueues last also enqueues k_stereo + k_median behind both (into twin output buffers).  The next jsorb_stereo_match
+// on the same pair with the same parameters and no extract in between finds the result finished (or nearly) and adopts it by
+// swapping the twin buffers in; anything else (other parameters, another partner, an extract in between, batches) runs the normal
+// path and the speculative result is dropped.  The outputs are the outputs of the same kernels on the same inputs either way.
+// Shared by the two handles; every field is guarded by `mu` (the two extract calls come from two host threads).
+struct jsorb_spec_state {
+    std::mutex mu;
+    jsorb_extractor *l = nullptr, *r = nullptr;
+    bool armed = false;
+    float mb = 0.f, mbf = 0.f;
+    int th_high = 0, th_low = 0;
+    unsigned long long l_base = 0, r_base = 0;   // extract sequence numbers of the two handles when the pair was armed (same frame)
+    bool inflight = false;                       // a speculative match is enqueued and not yet adopted or invalidated
+    unsigned long long l_seq = 0, r_seq = 0;     // the extracts it matched
+    bool wait_l = false, wait_r = false;         // the handle's next extract has to be ordered after the speculative kernels (they read its buffers)
+    hipEvent_t ev_done = nullptr;
+    long n_adopted = 0, n_dropped = 0;
+};
+
 struct jsorb_extractor {
     jsorb_params p{};
     Geometry g{};
@@ -110,6 +134,13 @@ struct jsorb_extractor {
     int use_frame_graph = 1;
     int32_t *deliver_kp_dev = nullptr;      // jsorb_extract_into: caller-owned device destinations of the next single-image pipeline
     uint8_t *deliver_desc_dev = nullptr;
+    // speculative stereo match of the synchronous single-frame call shape (struct jsorb_spec_state)
+    jsorb_spec_state *spec = nullptr;
+    unsigned long long spec_seq = 0;   // extract calls of this handle (written under spec->mu once paired)
+    bool spec_single = false;          // the last extract was a single image on an untimed handle
+    int speculate = 1;                 // JSORB_SPECULATE=0 / jsorb_set_speculative_stereo(l, 0) disable
+    float *sp_u = nullptr, *sp_d = nullptr, *h_sp_u = nullptr, *h_sp_d = nullptr;   // twin output buffers (left handle), swapped in on adoption
+    int *sp_stats = nullptr, *h_sp_stats = nullptr;
     ImageSrc src{};            // where level 0 of the last extract lives
     bool extracted = false, stereo_done = false;
     int stereo_pairs = 0;
@@ -520,6 +551,111 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
     return JSORB_OK;
 }
 
+StereoArgs make_stereo_args(float mb, float mbf, int th_high, int th_low)
+{
+    StereoArgs sa;
+    sa.maxD = mbf / mb;                  // const float maxD = mbf/minZ  (orb_stereo_match.cu:144-146)
+    sa.mbf = mbf;
+    sa.th_high = th_high;
+    sa.th_orb = (th_high + th_low) / 2;
+    return sa;
+}
+
+// ---- speculative stereo (struct jsorb_spec_state) ----
+// Before a handle's buffers are rewritten: the speculative kernels of the previous frame read them (both handles' keypoints,
+// descriptors, row tables and level images, the landing buffers included).  A single image is ordered on the GPU (its copy and
+// kernels go to e->stream); a batch, whose copies and lanes use other streams, waits on the host (rare: a pair that alternates
+// between the two call shapes).  Any new extract also invalidates a result nobody has asked for.
+int spec_guard(jsorb_extractor *e, int n)
+{
+    jsorb_spec_state *S = e->spec;
+    if (!S) return JSORB_OK;
+    std::lock_guard<std::mutex> lk(S->mu);
+    bool &need = e == S->l ? S->wait_l : S->wait_r;
+    if (need) {
+        if (n == 1) HIPCHK(e, hipStreamWaitEvent(e->stream, S->ev_done, 0));
+        else HIPCHK(e, hipEventSynchronize(S->ev_done));
+        need = false;
+    }
+    if (S->inflight) { S->inflight = false; S->n_dropped++; }
+    return JSORB_OK;
+}
+
+// After a handle has enqueued an extract.  The second of the two handles to get here for the same new frame enqueues the match.
+// Failures only disarm the pair (the caller's jsorb_stereo_match then runs the normal path and reports its own errors).
+void spec_after_extract(jsorb_extractor *e, int n)
+{
+    jsorb_spec_state *S = e->spec;
+    if (!S) { e->spec_seq++; return; }
+    std::lock_guard<std::mutex> lk(S->mu);
+    e->spec_seq++;
+    e->spec_single = n == 1 && !e->timing;
+    jsorb_extractor *l = S->l, *r = S->r;
+    if (!S->armed || !l->spec_single || !r->spec_single) return;
+    if (l->spec_seq - S->l_base != r->spec_seq - S->r_base || l->spec_seq == S->l_base) return;     // not the same new frame on both sides (yet)
+    hipStream_t st = l->lane_used[0];
+    bool ok = true;
+    if (r->lane_used[0] != st) ok = hipStreamWaitEvent(st, r->lane_done[0], 0) == hipSuccess;
+    if (ok) {
+        const StereoArgs sa = make_stereo_args(S->mb, S->mbf, S->th_high, S->th_low);
+        launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts, r->desc, r->row_tab,
+                      l->sp_u, l->sp_d, l->st_l1, l->st_aux, sa, 1, st);
+        launch_median(l->g, l->counts, l->sp_u, l->sp_d, l->st_l1, l->st_aux, l->sp_stats, 1, st, DeliverStereo{l->h_sp_u, l->h_sp_d, l->h_sp_stats});
+        ok = hipGetLastError() == hipSuccess && hipEventRecord(S->ev_done, st) == hipSuccess;
+        // whatever went out on the stream reads both handles' buffers: their next extracts are ordered after it in any case
+        S->wait_l = S->wait_r = true;
+    }
+    if (!ok) { S->armed = false; return; }
+    S->inflight = true;
+    S->l_seq = l->spec_seq;
+    S->r_seq = r->spec_seq;
+}
+
+void spec_detach(jsorb_spec_state *S)
+{
+    if (!S) return;
+    {
+        std::lock_guard<std::mutex> lk(S->mu);
+        S->armed = false;
+        if (S->wait_l || S->wait_r || S->inflight) (void)hipEventSynchronize(S->ev_done);
+    }
+    if (S->l) S->l->spec = nullptr;
+    if (S->r) S->r->spec = nullptr;
+    if (S->ev_done) (void)hipEventDestroy(S->ev_done);
+    delete S;
+}
+
+// Called by a synchronous single-pair jsorb_stereo_match that ran the normal path: from now on the pair is matched speculatively.
+int spec_arm(jsorb_extractor *l, jsorb_extractor *r, float mb, float mbf, int th_high, int th_low)
+{
+    if (l->spec && (l->spec->l != l || l->spec->r != r)) spec_detach(l->spec);
+    if (r->spec && (r->spec->l != l || r->spec->r != r)) spec_detach(r->spec);
+    if (!l->spec) {
+        const size_t B = (size_t)l->B, T = (size_t)l->g.T;
+        if (!l->sp_u) {
+            HIPCHK(l, hipMalloc(&l->sp_u, B * T * 4));
+            HIPCHK(l, hipMalloc(&l->sp_d, B * T * 4));
+            HIPCHK(l, hipMalloc(&l->sp_stats, B * 8 * sizeof(int)));
+            HIPCHK(l, hipHostMalloc(&l->h_sp_u, T * sizeof(float)));
+            HIPCHK(l, hipHostMalloc(&l->h_sp_d, T * sizeof(float)));
+            HIPCHK(l, hipHostMalloc(&l->h_sp_stats, B * 8 * sizeof(int)));
+        }
+        jsorb_spec_state *S = new (std::nothrow) jsorb_spec_state;
+        if (!S) { l->err = "out of memory (speculative stereo)"; return JSORB_ERR_HIP; }
+        if (hipEventCreateWithFlags(&S->ev_done, hipEventDisableTiming) != hipSuccess) { delete S; l->err = "hipEventCreate (speculative stereo)"; return JSORB_ERR_HIP; }
+        S->l = l; S->r = r;
+        l->spec = r->spec = S;
+    }
+    jsorb_spec_state *S = l->spec;
+    std::lock_guard<std::mutex> lk(S->mu);
+    S->armed = true;
+    S->mb = mb; S->mbf = mbf; S->th_high = th_high; S->th_low = th_low;
+    S->l_base = l->spec_seq;
+    S->r_base = r->spec_seq;
+    if (S->inflight) { S->inflight = false; S->n_dropped++; }
+    return JSORB_OK;
+}
+
 bool check_image(const jsorb_extractor *e, int image) { return e && e->extracted && image >= 0 && image < e->n_images; }
 
 } // namespace
@@ -559,6 +695,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));      // tuning hooks
     if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
     if (const char *sw = getenv("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
+    if (const char *sp = getenv("JSORB_SPECULATE")) e->speculate = atoi(sp);
     if (const char *tr = getenv("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
     if (const char *fg = getenv("JSORB_FRAME_GRAPH")) e->use_frame_graph = atoi(fg);
     if (const char *mp = getenv("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
@@ -689,6 +826,7 @@ void jsorb_destroy(jsorb_extractor *e)
                 e->th_n, e->th_h2d / e->th_n, e->th_enq / e->th_n, e->th_wait / e->th_n, e->th_st_n, e->th_st_n ? e->th_st_enq / e->th_st_n : 0.0,
                 e->th_st_n ? e->th_st_wait / e->th_st_n : 0.0);
     (void)hipSetDevice(e->device);
+    spec_detach(e->spec);        // waits for a speculative match that still reads this handle's buffers; the partner continues unpaired
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     if (e->has_readers)       // a stereo match enqueued through another handle may still be reading this handle's buffers
         for (int j = 0; j < e->readers_K; j++) (void)hipEventSynchronize(e->lane_readers_done[j]);
@@ -697,11 +835,11 @@ void jsorb_destroy(jsorb_extractor *e)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->sp_u, e->sp_d, e->sp_stats, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
-    for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d})
+    for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d, (void *)e->h_sp_u, (void *)e->h_sp_d, (void *)e->h_sp_stats})
         if (hp) (void)hipHostFree(hp);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -795,11 +933,8 @@ static int mark_buffer_consumed(jsorb_extractor *e, int k)
     return JSORB_OK;
 }
 
-int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
+static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
 {
-    if (!e || !host_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
-    e->mirror_valid = e->st_mirror_valid = false;
-    HIPCHK(e, hipSetDevice(e->device));
     const LevelDesc &l0 = e->g.lv[0];
     const size_t img_bytes = (size_t)l0.H * l0.W;
     int rc;
@@ -846,11 +981,20 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     return run_pipeline(e, n_images);
 }
 
-int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)
+int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
 {
-    if (!e || !dev_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
+    if (!e || !host_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
     e->mirror_valid = e->st_mirror_valid = false;
     HIPCHK(e, hipSetDevice(e->device));
+    int rc = spec_guard(e, n_images);
+    if (rc) return rc;
+    if ((rc = extract_batch_host_enqueue(e, host_images, image_stride, step, n_images))) return rc;
+    spec_after_extract(e, n_images);
+    return JSORB_OK;
+}
+
+static int extract_batch_device_enqueue(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)
+{
     const LevelDesc &l0 = e->g.lv[0];
     const bool in_place = (step % 16 == 0) && (((uintptr_t)dev_images) % 16 == 0) && (image_stride % 16 == 0);   // kernels stage with 16-byte loads
     if (in_place) {   // level 0 is read where it lies: no copy of the grayscale plane
@@ -864,12 +1008,44 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     return run_pipeline(e, n_images);
 }
 
-// Tail of the synchronous single-frame calls: ONE stream synchronisation - counts, keypoints and descriptors were written into the
-// pinned mirrors (and the caller's device buffers) by the kernels themselves.
+int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)
+{
+    if (!e || !dev_images || n_images < 1 || n_images > e->B || step < e->g.lv[0].W) return JSORB_ERR_INVALID;
+    e->mirror_valid = e->st_mirror_valid = false;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = spec_guard(e, n_images);
+    if (rc) return rc;
+    if ((rc = extract_batch_device_enqueue(e, dev_images, image_stride, step, n_images))) return rc;
+    spec_after_extract(e, n_images);
+    return JSORB_OK;
+}
+
+// Waits for an event by polling first (a frame is ~100 us of GPU time; a blocking wait adds tens of microseconds of wake-up latency)
+static int wait_event(jsorb_extractor *e, hipEvent_t ev, bool spin)
+{
+    if (spin)
+        for (int it = 0; it < 400000; it++) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) return JSORB_OK;
+            if (q != hipErrorNotReady) { e->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return JSORB_ERR_HIP; }
+            __builtin_ia32_pause();
+        }
+    HIPCHK(e, hipEventSynchronize(ev));
+    return JSORB_OK;
+}
+
+// Tail of the synchronous single-frame calls: ONE wait - counts, keypoints and descriptors were written into the pinned mirrors (and
+// the caller's device buffers) by the kernels themselves.  The wait is for the event behind the extract kernels, not for the stream:
+// the other extractor's thread may already have put this frame's speculative stereo match on it (struct jsorb_spec_state).
 static int finish_single_frame(jsorb_extractor *e, int *n_keypoints)
 {
     const double t0 = e->trace_host ? now_us() : 0.0;
-    int rc = jsorb_sync(e);
+    int rc;
+    if (e->timing || e->K != 1) rc = jsorb_sync(e);
+    else if (!(rc = wait_event(e, e->lane_done[0], e->spin_wait != 0))) {
+        e->counts_synced = true;
+        if (e->mirror_pending) { e->mirror_valid = true; e->mirror_pending = false; }
+    }
     if (e->trace_host) e->th_wait += now_us() - t0;
     if (rc) return rc;
     if (n_keypoints) *n_keypoints = e->h_counts[JSORB_MAX_LEVELS];
@@ -1071,11 +1247,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
     }
     HIPCHK(l, hipSetDevice(l->device));
     const int n = l->n_images;
-    StereoArgs sa;
-    sa.maxD = mbf / mb;                  // const float maxD = mbf/minZ  (orb_stereo_match.cu:144-146)
-    sa.mbf = mbf;
-    sa.th_high = th_high;
-    sa.th_orb = (th_high + th_low) / 2;
+    const StereoArgs sa = make_stereo_args(mb, mbf, th_high, th_low);
     // Lane j of the left handle matches its own pairs as soon as lane j of the right handle has finished them (both handles split
     // the same n into the same lanes); with different partitions every left lane waits for all right lanes.
     const bool aligned = l->K == r->K;
@@ -1180,15 +1352,57 @@ int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float m
 {
     if (!l || !r) return JSORB_ERR_INVALID;
     const double t0 = l->trace_host ? now_us() : 0.0;
-    int rc = jsorb_stereo_match_batch_async(l, r, mb, mbf, th_high, th_low);
-    if (rc) return rc;
-    const double t1 = l->trace_host ? now_us() : 0.0;
-    rc = jsorb_sync(l);
-    if (rc) return rc;
-    if (l->trace_host) { l->th_st_enq += t1 - t0; l->th_st_wait += now_us() - t1; l->th_st_n++; }
+    int rc;
+    bool adopt = false;
+    if (jsorb_spec_state *S = l->spec) {
+        // this very match may already be on the GPU, enqueued behind the two extracts (struct jsorb_spec_state)
+        std::lock_guard<std::mutex> lk(S->mu);
+        adopt = S->l == l && S->r == r && S->inflight && S->l_seq == l->spec_seq && S->r_seq == r->spec_seq && S->mb == mb && S->mbf == mbf &&
+                S->th_high == th_high && S->th_low == th_low && l->extracted && r->extracted && l->n_images == 1 && r->n_images == 1 && !l->stereo_done;
+        if (adopt) { S->inflight = false; S->n_adopted++; }
+    }
+    if (adopt) {
+        HIPCHK(l, hipSetDevice(l->device));
+        const double t1 = l->trace_host ? now_us() : 0.0;
+        if ((rc = wait_event(l, l->spec->ev_done, l->spin_wait != 0))) return rc;
+        if (!l->counts_synced && (rc = jsorb_sync(l))) return rc;          // extracts enqueued through the asynchronous calls
+        std::swap(l->st_u, l->sp_u); std::swap(l->st_d, l->sp_d); std::swap(l->st_stats, l->sp_stats);
+        std::swap(l->h_u, l->h_sp_u); std::swap(l->h_d, l->h_sp_d); std::swap(l->h_stats, l->h_sp_stats);
+        l->stereo_done = true;
+        l->stereo_pairs = 1;
+        l->st_mirror_valid = true;
+        l->st_mirror_pending = false;
+        if (l->trace_host) { l->th_st_enq += t1 - t0; l->th_st_wait += now_us() - t1; l->th_st_n++; }
+    } else {
+        rc = jsorb_stereo_match_batch_async(l, r, mb, mbf, th_high, th_low);
+        if (rc) return rc;
+        const double t1 = l->trace_host ? now_us() : 0.0;
+        rc = jsorb_sync(l);
+        if (rc) return rc;
+        if (l->trace_host) { l->th_st_enq += t1 - t0; l->th_st_wait += now_us() - t1; l->th_st_n++; }
+        if (l != r && l->speculate && l->n_images == 1 && !l->timing && !r->timing && (rc = spec_arm(l, r, mb, mbf, th_high, th_low))) return rc;
+    }
     rc = jsorb_copy_stereo(l, 0, u_right, depth, stats);
     if (rc) return rc;
     if (stats) stats->n_right = jsorb_n_keypoints(r, 0);
+    return JSORB_OK;
+}
+
+int jsorb_set_speculative_stereo(jsorb_extractor *l, int on)
+{
+    if (!l) return JSORB_ERR_INVALID;
+    l->speculate = on ? 1 : 0;
+    if (!on && l->spec) { (void)hipSetDevice(l->device); spec_detach(l->spec); }
+    return JSORB_OK;
+}
+
+int jsorb_speculative_stereo_stats(const jsorb_extractor *l, long *n_adopted, long *n_dropped)
+{
+    if (!l) return JSORB_ERR_INVALID;
+    long a = 0, d = 0;
+    if (jsorb_spec_state *S = l->spec) { std::lock_guard<std::mutex> lk(S->mu); a = S->n_adopted; d = S->n_dropped; }
+    if (n_adopted) *n_adopted = a;
+    if (n_dropped) *n_dropped = d;
     return JSORB_OK;
 }
 

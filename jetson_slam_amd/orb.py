@@ -28,7 +28,7 @@ EXPORTS = [
     "jsorb_copy_descriptors", "jsorb_n_levels", "jsorb_level_dims", "jsorb_level_tiles", "jsorb_total_tiles", "jsorb_scale",
     "jsorb_inv_scale", "jsorb_level_image_device", "jsorb_copy_level_image", "jsorb_copy_tile_candidates", "jsorb_copy_angles",
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
-    "jsorb_copy_stereo", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
+    "jsorb_copy_stereo", "jsorb_set_speculative_stereo", "jsorb_speculative_stereo_stats", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
     "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
     "jsorb_unpack_frame", "jsorb_assign_features_to_grid", "jsorb_copy_level_mask",
     "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
@@ -108,6 +108,8 @@ def load_library(path=None):
         "jsorb_stereo_depth_device": (P, [P, I]),
         "jsorb_copy_stereo": (I, [P, I, P, P, C.POINTER(JsorbStereoStats)]),
         "jsorb_gather_counts_async": (I, [P, P, P]),
+        "jsorb_set_speculative_stereo": (I, [P, I]),
+        "jsorb_speculative_stereo_stats": (I, [P, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "jsorb_set_stream": (I, [P, P]),
         "jsorb_get_stream": (P, [P]),
         "jsorb_stream_wait_done": (I, [P, P]),
@@ -376,6 +378,18 @@ def compute_stereo_matches(left, right, mb, mbf, th_high=TH_HIGH, th_low=TH_LOW)
     rc = left._lib.jsorb_stereo_match(left.handle, right.handle, mb, mbf, th_high, th_low, u.ctypes.data, d.ctypes.data, C.byref(st))
     left._chk(rc)
     return u[:n], d[:n], {k: getattr(st, k) for k, _ in JsorbStereoStats._fields_}
+
+
+def set_speculative_stereo(left, on):
+    """jsorb_set_speculative_stereo: the match enqueued behind the next pair of single-image extracts (include/jsorb.h)"""
+    left._chk(left._lib.jsorb_set_speculative_stereo(left.handle, int(bool(on))))
+
+
+def speculative_stereo_stats(left):
+    """(adopted, dropped) speculative matches of the pair this left handle belongs to"""
+    a, d = C.c_long(0), C.c_long(0)
+    left._chk(left._lib.jsorb_speculative_stereo_stats(left.handle, C.byref(a), C.byref(d)))
+    return a.value, d.value
 
 
 def stereo_match_batch_async(left, right, mb, mbf, th_high=TH_HIGH, th_low=TH_LOW):

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -48,11 +49,24 @@ int main(int argc, char **argv)
         const double t4 = now_us();
         if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; }
     }
+    // how many of the matches were the ones the library had already enqueued behind the extracts (include/jsorb.h,
+    // jsorb_set_speculative_stereo), and: the same frame once more with the feature off must give the same bits
+    long adopted = 0, dropped = 0;
+    jsorb_speculative_stereo_stats(exL.handle(), &adopted, &dropped);
+    std::vector<float> u_spec = mvuRight, d_spec = mvDepth, u_ref, d_ref;
+    jsorb_set_speculative_stereo(exL.handle(), 0);
+    exL.extract(imL.data(), W, kpL, dL); exR.extract(imR.data(), W, kpR, dR);
+    Jetson_SLAM::ComputeStereoMatches(exL, exR, mbf / fx, mbf, u_ref, d_ref);
+    const bool same = u_ref.size() == u_spec.size() && d_ref.size() == d_spec.size() && !u_ref.empty() &&
+                      memcmp(u_ref.data(), u_spec.data(), u_ref.size() * sizeof(float)) == 0 && memcmp(d_ref.data(), d_spec.data(), d_ref.size() * sizeof(float)) == 0;
+    if (!same) { fprintf(stderr, "speculative and plain stereo results differ\n"); return 3; }
     if (getenv("JSORB_JSON"))
-        printf("{\"frames\": %d, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f}\n", frames,
-               t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames);
+        printf("{\"frames\": %d, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
+               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames,
+               t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped);
     else
-    printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f\n",
-           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames);
+    printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f ; "
+           "speculative matches adopted %ld / dropped %ld\n",
+           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped);
     return 0;
 }
