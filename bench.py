@@ -471,7 +471,8 @@ def measure_frame_latency(cfg, left, right, frames=300):
                            "adopted by ComputeStereoMatches - total_us_plain is the same driver with JSORB_SPECULATE=0")
             out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=dict(env, JSORB_SPECULATE="0"),
                                  capture_output=True, text=True, timeout=120)
-            res["total_us_plain"] = json.loads(out.stdout.strip().splitlines()[-1])["total_us"]
+            plain = json.loads(out.stdout.strip().splitlines()[-1])
+            res["total_us_plain"], res["total_us_median_plain"] = plain["total_us"], plain["total_us_median"]
             return res
         except Exception as e:      # never let a side measurement break the contract line
             return {"error": str(e)[:200]}

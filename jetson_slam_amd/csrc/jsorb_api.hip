@@ -140,7 +140,8 @@ struct jsorb_extractor {
     bool spec_single = false;          // the last extract was a single image on an untimed handle
     int speculate = 1;                 // JSORB_SPECULATE=0 / jsorb_set_speculative_stereo(l, 0) disable
     float *sp_u = nullptr, *sp_d = nullptr, *h_sp_u = nullptr, *h_sp_d = nullptr;   // twin output buffers (left handle), swapped in on adoption
-    int *sp_stats = nullptr, *h_sp_stats = nullptr;
+    int *sp_stats = nullptr, *h_sp_stats = nullptr, *sp_l1 = nullptr;   // sp_l1 / sp_aux: scratch of the speculative match (one pair)
+    unsigned *sp_aux = nullptr;
     ImageSrc src{};            // where level 0 of the last extract lives
     bool extracted = false, stereo_done = false;
     int stereo_pairs = 0;
@@ -593,14 +594,18 @@ void spec_after_extract(jsorb_extractor *e, int n)
     jsorb_extractor *l = S->l, *r = S->r;
     if (!S->armed || !l->spec_single || !r->spec_single) return;
     if (l->spec_seq - S->l_base != r->spec_seq - S->r_base || l->spec_seq == S->l_base) return;     // not the same new frame on both sides (yet)
-    hipStream_t st = l->lane_used[0];
+    // on the stream of the extract that was enqueued LAST (this one): it is the one that finishes last, so the match follows it in stream
+    // order and the event of the other extract has usually fired by then (a cross-stream wait that is still pending when the GPU
+    // reaches it costs ~20 us of idle time on this path).  Own scratch: a normal match on l's stream may follow while this one runs.
+    jsorb_extractor *other = e == l ? r : l;
+    hipStream_t st = e->lane_used[0];
     bool ok = true;
-    if (r->lane_used[0] != st) ok = hipStreamWaitEvent(st, r->lane_done[0], 0) == hipSuccess;
+    if (other->lane_used[0] != st) ok = hipStreamWaitEvent(st, other->lane_done[0], 0) == hipSuccess;
     if (ok) {
         const StereoArgs sa = make_stereo_args(S->mb, S->mbf, S->th_high, S->th_low);
         launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts, r->desc, r->row_tab,
-                      l->sp_u, l->sp_d, l->st_l1, l->st_aux, sa, 1, st);
-        launch_median(l->g, l->counts, l->sp_u, l->sp_d, l->st_l1, l->st_aux, l->sp_stats, 1, st, DeliverStereo{l->h_sp_u, l->h_sp_d, l->h_sp_stats});
+                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st);
+        launch_median(l->g, l->counts, l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, l->sp_stats, 1, st, DeliverStereo{l->h_sp_u, l->h_sp_d, l->h_sp_stats});
         ok = hipGetLastError() == hipSuccess && hipEventRecord(S->ev_done, st) == hipSuccess;
         // whatever went out on the stream reads both handles' buffers: their next extracts are ordered after it in any case
         S->wait_l = S->wait_r = true;
@@ -636,6 +641,8 @@ int spec_arm(jsorb_extractor *l, jsorb_extractor *r, float mb, float mbf, int th
             HIPCHK(l, hipMalloc(&l->sp_u, B * T * 4));
             HIPCHK(l, hipMalloc(&l->sp_d, B * T * 4));
             HIPCHK(l, hipMalloc(&l->sp_stats, B * 8 * sizeof(int)));
+            HIPCHK(l, hipMalloc(&l->sp_l1, T * 4));
+            HIPCHK(l, hipMalloc(&l->sp_aux, T * 4));
             HIPCHK(l, hipHostMalloc(&l->h_sp_u, T * sizeof(float)));
             HIPCHK(l, hipHostMalloc(&l->h_sp_d, T * sizeof(float)));
             HIPCHK(l, hipHostMalloc(&l->h_sp_stats, B * 8 * sizeof(int)));
@@ -835,7 +842,7 @@ void jsorb_destroy(jsorb_extractor *e)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->sp_u, e->sp_d, e->sp_stats, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
@@ -933,8 +940,10 @@ static int mark_buffer_consumed(jsorb_extractor *e, int k)
     return JSORB_OK;
 }
 
-static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images)
+// *mark: the landing buffer whose "consumed" events the caller records after everything else it enqueues for this call (-1: none)
+static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images, int *mark)
 {
+    *mark = -1;
     const LevelDesc &l0 = e->g.lv[0];
     const size_t img_bytes = (size_t)l0.H * l0.W;
     int rc;
@@ -950,7 +959,8 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         if ((rc = run_pipeline(e, n_images))) return rc;
         if (e->trace_host) { e->th_h2d += t1 - t0; e->th_enq += now_us() - t1; e->th_n++; }
         e->stage_cur = 1;       // a following batch call starts on the other buffer
-        return mark_buffer_consumed(e, 0);
+        *mark = 0;
+        return JSORB_OK;
     }
     if (e->stage[0] && step == l0.W && image_stride == img_bytes) {
         // dense batch: ONE pinned hipMemcpyAsync for all images on the copy stream, then level 0 is read in place from the landing
@@ -972,7 +982,8 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         e->src.l0 = e->stage[k]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
         if ((rc = run_pipeline(e, n_images, e->ev_copied[k]))) return rc;
         e->stage_cur = k ^ 1;
-        return mark_buffer_consumed(e, k);
+        *mark = k;
+        return JSORB_OK;
     }
     // strided input: one 2-D copy per image into the pitched slab, enqueued by run_pipeline on the stream of the lane that owns the image
     e->copy_src = host_images; e->copy_stride = image_stride; e->copy_step = step; e->copy_kind = 1;
@@ -988,9 +999,12 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     HIPCHK(e, hipSetDevice(e->device));
     int rc = spec_guard(e, n_images);
     if (rc) return rc;
-    if ((rc = extract_batch_host_enqueue(e, host_images, image_stride, step, n_images))) return rc;
+    int mark;
+    if ((rc = extract_batch_host_enqueue(e, host_images, image_stride, step, n_images, &mark))) return rc;
+    // the speculative match goes out first: every packet between the extract kernels and k_stereo (an event record is a barrier
+    // packet, ~5 us on the GPU's command processor) delays the match
     spec_after_extract(e, n_images);
-    return JSORB_OK;
+    return mark >= 0 ? mark_buffer_consumed(e, mark) : JSORB_OK;
 }
 
 static int extract_batch_device_enqueue(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)

@@ -23,6 +23,12 @@ def po():
 @pytest.fixture(scope="session")
 def orb():
     """the product binding; only GPU tests may create extractors through it"""
+    # torch (device buffers, streams and collectives of some tests) brings up its HIP context before the library does: the order
+    # bench.py uses.  (A filtered run in which torch's first device call came late - after the library, host threads and child
+    # processes - saw torch report "no ROCm-capable device" on the test box; the full-suite order never did.)
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     from jetson_slam_amd import orb as _orb
     return _orb
 

@@ -1,6 +1,7 @@
 // Per-frame latency of the reference-shaped synchronous API from C++ (no Python in the loop): what Frame::Frame's stereo
 // constructor costs per frame.  Usage: frame_latency H W L tile th fx bf left.raw right.raw [frames]
 // Build: g++ -O2 -std=c++17 -I include tools/micro/frame_latency.cpp -L jetson_slam_amd -ljsorb -lpthread -Wl,-rpath,$PWD/jetson_slam_amd
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,7 @@ int main(int argc, char **argv)
     std::vector<jsorb_keypoint> keys, keysR;
     std::vector<unsigned char> desc, descR;
     double t_ext = 0, t_cpu = 0, t_st = 0, t_unp = 0;
+    std::vector<double> per_frame;
     for (int it = -20; it < frames; it++) {
         const double t0 = now_us();
         std::thread tl([&] { exL.extract(imL.data(), W, kpL, dL); });   // Frame.cpp:107-110
@@ -47,7 +49,7 @@ int main(int argc, char **argv)
         const double t3 = now_us();
         Jetson_SLAM::UnpackFrame(exL, keys, desc); Jetson_SLAM::UnpackFrame(exR, keysR, descR);      // alternative to the four to_cpu()
         const double t4 = now_us();
-        if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; }
+        if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; per_frame.push_back(t3 - t0); }
     }
     // how many of the matches were the ones the library had already enqueued behind the extracts (include/jsorb.h,
     // jsorb_set_speculative_stereo), and: the same frame once more with the feature off must give the same bits
@@ -60,13 +62,15 @@ int main(int argc, char **argv)
     const bool same = u_ref.size() == u_spec.size() && d_ref.size() == d_spec.size() && !u_ref.empty() &&
                       memcmp(u_ref.data(), u_spec.data(), u_ref.size() * sizeof(float)) == 0 && memcmp(d_ref.data(), d_spec.data(), d_ref.size() * sizeof(float)) == 0;
     if (!same) { fprintf(stderr, "speculative and plain stereo results differ\n"); return 3; }
+    std::sort(per_frame.begin(), per_frame.end());
+    const double med = per_frame.empty() ? 0.0 : per_frame[per_frame.size() / 2], p90 = per_frame.empty() ? 0.0 : per_frame[per_frame.size() * 9 / 10];
     if (getenv("JSORB_JSON"))
-        printf("{\"frames\": %d, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
-               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames,
+        printf("{\"frames\": %d, \"total_us_median\": %.1f, \"total_us_p90\": %.1f, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
+               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames, med, p90,
                t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped);
     else
     printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f ; "
-           "speculative matches adopted %ld / dropped %ld\n",
-           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped);
+           "speculative matches adopted %ld / dropped %ld ; median %.1f, p90 %.1f\n",
+           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped, med, p90);
     return 0;
 }
