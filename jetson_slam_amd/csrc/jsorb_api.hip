@@ -32,6 +32,15 @@ const char *k_names[JSORB_K_COUNT] = {"k_pyramid", "k_detect", "k_compact", "k_b
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
+// HIP multiplexes every stream of a process over GPU_MAX_HW_QUEUES hardware queues (default 4), and a stream that waits for an event
+// holds up every other stream that shares its queue.  This library runs 4 lane streams + 1 upload stream + one main stream per handle;
+// on 4 queues which of them share is decided by creation order (measured with otherwise identical code, only the number of idle streams
+// created earlier differing: 85.7 k against 91.4 k pairs/s device-resident, 47 k against 71 k host-streamed).  Sixteen queues give every
+// stream of a few handle pairs its own (8 were not enough for bench.py, which keeps two sets of handles alive).  The variable is read when the HIP runtime initialises (its first API call), so this
+// constructor - run when the library is loaded - is early enough for a process that links the library or imports the Python binding
+// before it touches the GPU; an explicit setting by the user wins.  ("Runtime environment")
+__attribute__((constructor)) void jsorb_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 } // namespace
 
 // Stereo match enqueued AHEAD of the call that asks for it (the synchronous single-frame call shape, Frame.cpp:107-125: extract L and R
@@ -96,7 +105,8 @@ struct jsorb_extractor {
     // host uploads: two dense B x H0 x W0 landing buffers filled by ONE hipMemcpyAsync per batch on a dedicated copy stream, then read
     // in place as level 0.  Double buffering lets the upload of batch k+1 overlap the kernels of batch k.
     uint8_t *stage[2] = {nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
+    int host_lanes = 2;                     // cap on the lanes of a host-uploaded batch (JSORB_HOST_LANES): PCIe-bound, see extract_batch_host_enqueue
+    int lane_cap = JSORB_MAX_LANES;         // transient: cap for the batch being enqueued
     hipEvent_t ev_copied[2][JSORB_MAX_LANES] = {};   // per landing buffer and lane: the lane's images have arrived
     int consumed_n[2] = {0, 0};        // images of the batch that last used the buffer (with consumed_K: its lane partition)
     hipEvent_t ev_consumed[2][JSORB_MAX_LANES] = {};   // per landing buffer and lane
@@ -385,6 +395,7 @@ int drain_timed(jsorb_extractor *e)
 struct LanePool {
     std::mutex m;
     hipStream_t s[JSORB_MAX_LANES] = {};
+    hipStream_t copy = nullptr;     // uploads of host batches, all handles: see pool_copy_stream
 };
 LanePool g_pool[16];
 
@@ -397,6 +408,23 @@ int pool_stream(jsorb_extractor *e, int j, hipStream_t *out)
     return JSORB_OK;
 }
 
+// ONE upload stream per device for the host batches of every handle.  The regime is PCIe-bound, so the ORDER of the uploads is what
+// matters: left chunks then right chunks, each at full bandwidth, in the order the lanes consume them.  With a copy stream per handle
+// the left and right uploads ran concurrently on two SDMA engines at half speed each and every lane got its images later.
+int pool_copy_stream(jsorb_extractor *e, hipStream_t *out)
+{
+    LanePool &p = g_pool[e->device & 15];
+    std::lock_guard<std::mutex> lk(p.m);
+    if (!p.copy) {
+        int least = 0, greatest = 0;
+        HIPCHK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = getenv("JSORB_COPY_PRIORITY") ? std::max(greatest, std::min(least, atoi(getenv("JSORB_COPY_PRIORITY")))) : greatest;
+        HIPCHK(e, hipStreamCreateWithPriority(&p.copy, hipStreamNonBlocking, prio));
+    }
+    *out = p.copy;
+    return JSORB_OK;
+}
+
 inline hipStream_t lane_stream(const jsorb_extractor *e, int j) { return e->lane_used[j]; }      // of the LAST batch
 
 // Split n images into contiguous lanes.  A lane keeps at least ~7 Mpx of level-0 pixels (about 20 images of 752x480) so that each
@@ -405,7 +433,7 @@ int plan_lanes(const jsorb_extractor *e, int n, int *first)
 {
     const double px = (double)e->g.lv[0].H * e->g.lv[0].W;
     const int min_per_lane = std::max(1, (int)std::ceil(e->lane_min_px / px));
-    int K = std::min(e->max_lanes, n / min_per_lane);
+    int K = std::min(std::min(e->max_lanes, e->lane_cap), n / min_per_lane);
     if (K < 1 || e->timing) K = 1;
     // lane sizes in units of 8 images where possible: the XCD-aware workgroup mapping (xcd_map) pads a launch to a multiple of 8 images,
     // and 43 + 43 + 42 images cost 10 % more workgroup slots than 48 + 40 + 40 (measured: 3 uneven lanes 77.8 k, 4 even lanes 84.8 k pairs/s)
@@ -703,6 +731,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
     if (const char *sw = getenv("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
     if (const char *sp = getenv("JSORB_SPECULATE")) e->speculate = atoi(sp);
+    if (const char *hl = getenv("JSORB_HOST_LANES")) e->host_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(hl)));
     if (const char *tr = getenv("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
     if (const char *fg = getenv("JSORB_FRAME_GRAPH")) e->use_frame_graph = atoi(fg);
     if (const char *mp = getenv("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
@@ -722,7 +751,6 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     HIPCHK(e, hipMemset(e->slab, 0, slab_total));
     HIPCHK(e, hipMemset(e->blur, 0, slab_total));   // blurred image is 0 outside the ROI (Appendix C-2)
     if (g.lv[0].W % 16 == 0) {
-        HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
             HIPCHK(e, hipMalloc(&e->stage[k], B * (size_t)g.lv[0].H * g.lv[0].W + 256));
             for (int j = 0; j < JSORB_MAX_LANES; j++) {
@@ -862,7 +890,12 @@ void jsorb_destroy(jsorb_extractor *e)
             if (e->ev_consumed[k][j]) (void)hipEventDestroy(e->ev_consumed[k][j]);
         }
     }
-    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    {   // uploads of this handle still in flight on the device's copy stream read caller memory and write the landing buffers
+        LanePool &lp = g_pool[e->device & 15];
+        hipStream_t cs;
+        { std::lock_guard<std::mutex> lk(lp.m); cs = lp.copy; }
+        if (cs) (void)hipStreamSynchronize(cs);
+    }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -968,19 +1001,27 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         // The upload is cut at the lane boundaries of the batch: lane j starts as soon as ITS images have landed, and its part of the
         // buffer is refilled as soon as lane j of the batch that used the buffer two batches ago (extract kernels and, if any, the
         // stereo match) has finished - the copy engine never waits for a whole batch.
+        // At most two lanes: the regime is PCIe-bound (a pair is 722 kB; 57 GB/s = 79 k pairs/s against 91 k for the kernels), so the
+        // kernels do not need the overlap of 4 lanes, and coarser chunks measured better (8 hardware queues, 128 / 256 pairs per batch:
+        // 2 lanes 65 / 74 k, 3 lanes 59 / 65 k, 4 lanes 48 / 58 k pairs/s).
         const int k = e->stage_cur;
         int first[JSORB_MAX_LANES + 1];
+        e->lane_cap = e->host_lanes;
         const int K = plan_lanes(e, n_images, first);
+        hipStream_t cs = nullptr;
+        if ((rc = pool_copy_stream(e, &cs))) { e->lane_cap = JSORB_MAX_LANES; return rc; }
         const bool same_split = e->consumed_K[k] == K && e->consumed_n[k] == n_images;
-        if (!same_split && (rc = wait_buffer_consumed(e, k, e->copy_stream))) return rc;
+        if (!same_split && (rc = wait_buffer_consumed(e, k, cs))) { e->lane_cap = JSORB_MAX_LANES; return rc; }
         for (int j = 0; j < K; j++) {
-            if (same_split) HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->ev_consumed[k][j], 0));
+            if (same_split) HIPCHK(e, hipStreamWaitEvent(cs, e->ev_consumed[k][j], 0));
             HIPCHK(e, hipMemcpyAsync(e->stage[k] + (size_t)first[j] * img_bytes, host_images + (size_t)first[j] * img_bytes,
-                                     img_bytes * (size_t)(first[j + 1] - first[j]), hipMemcpyHostToDevice, e->copy_stream));
-            HIPCHK(e, hipEventRecord(e->ev_copied[k][j], e->copy_stream));
+                                     img_bytes * (size_t)(first[j + 1] - first[j]), hipMemcpyHostToDevice, cs));
+            HIPCHK(e, hipEventRecord(e->ev_copied[k][j], cs));
         }
         e->src.l0 = e->stage[k]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
-        if ((rc = run_pipeline(e, n_images, e->ev_copied[k]))) return rc;
+        rc = run_pipeline(e, n_images, e->ev_copied[k]);
+        e->lane_cap = JSORB_MAX_LANES;
+        if (rc) return rc;
         e->stage_cur = k ^ 1;
         *mark = k;
         return JSORB_OK;
@@ -999,6 +1040,7 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
     HIPCHK(e, hipSetDevice(e->device));
     int rc = spec_guard(e, n_images);
     if (rc) return rc;
+    e->lane_cap = JSORB_MAX_LANES;
     int mark;
     if ((rc = extract_batch_host_enqueue(e, host_images, image_stride, step, n_images, &mark))) return rc;
     // the speculative match goes out first: every packet between the extract kernels and k_stereo (an event record is a barrier
@@ -1029,6 +1071,7 @@ int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_imag
     HIPCHK(e, hipSetDevice(e->device));
     int rc = spec_guard(e, n_images);
     if (rc) return rc;
+    e->lane_cap = JSORB_MAX_LANES;
     if ((rc = extract_batch_device_enqueue(e, dev_images, image_stride, step, n_images))) return rc;
     spec_after_extract(e, n_images);
     return JSORB_OK;

@@ -11,6 +11,9 @@ There is no CPU fallback here: if libjsorb.so or a gfx950 device is missing the 
 import ctypes as C
 import os
 
+# the library's default for the HIP runtime (csrc/jsorb_api.hip, jsorb_runtime_defaults); effective when nothing has touched the GPU yet
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # the library's default for the HIP runtime; torch initialises HIP first here
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
