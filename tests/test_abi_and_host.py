@@ -138,3 +138,16 @@ def test_compat_header_covers_the_whole_syncedmem_surface():
                    "void set_zero_gpu_async(void)", "void set_zero_cpu(void)", "int count_;", "int capacity_;", "Dtype *cpu_data_;", "Dtype *gpu_data_;",
                    "size_t pitch_;", "cudaStream_t cu_stream_;", "cudaError_t cu_error_;"):
         assert member in src, member
+
+
+def test_library_sets_its_hip_runtime_default_and_respects_the_users(libpath):
+    """jsorb_api.hip, jsorb_runtime_defaults: loading libjsorb.so sets GPU_MAX_HW_QUEUES=16 (HIP's default of 4 hardware queues makes
+    the library's lane / upload / main streams share queues by accident of creation order) unless the variable is
+    already set.  Checked in child processes through the C runtime's own environment (os.environ is a snapshot taken at start-up)."""
+    import subprocess, sys
+    code = ("import ctypes, sys; ctypes.CDLL(%r); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "v = libc.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else 'unset')") % libpath
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "4"
