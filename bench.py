@@ -485,6 +485,10 @@ def measure_frame_latency(cfg, left, right, frames=300):
                                  capture_output=True, text=True, timeout=120)
             plain = json.loads(out.stdout.strip().splitlines()[-1])
             res["total_us_plain"], res["total_us_median_plain"] = plain["total_us"], plain["total_us_median"]
+            # not the reference's code shape: the same frame with the two extractor threads kept alive instead of spawned per frame
+            out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=dict(env, JSORB_PERSISTENT_THREADS="1"),
+                                 capture_output=True, text=True, timeout=120)
+            res["total_us_median_persistent_threads"] = json.loads(out.stdout.strip().splitlines()[-1])["total_us_median"]
             return res
         except Exception as e:      # never let a side measurement break the contract line
             return {"error": str(e)[:200]}
