@@ -141,6 +141,9 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *left, jsorb_extractor *right
 const float *jsorb_stereo_uright_device(const jsorb_extractor *left, int image);
 const float *jsorb_stereo_depth_device(const jsorb_extractor *left, int image);
 int jsorb_copy_stereo(const jsorb_extractor *left, int image, float *u_right, float *depth, jsorb_stereo_stats *stats);
+/* Inspection (tests): the L1 window distance of the accepted sub-pixel refinement per left keypoint, -1 = none - the values the median
+ * cut of orb_stereo_match.cu:560-580 sorts (vDistIdx[].first), N_left int32. */
+int jsorb_copy_stereo_l1(const jsorb_extractor *left, int image, int32_t *host_dst);
 /* Multi-GPU batch mode: write (N_left, N_right, N_matched) of every pair of the last batch, 3 int32 per pair, to a DEVICE
  * buffer (enqueued on left's stream) - the payload of the one collective of this path, an all-gather of per-pair counts. */
 int jsorb_gather_counts_async(jsorb_extractor *left, jsorb_extractor *right, int32_t *dev_dst);

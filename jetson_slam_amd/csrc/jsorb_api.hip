@@ -150,6 +150,7 @@ struct jsorb_extractor {
     bool spec_single = false;          // the last extract was a single image on an untimed handle
     int speculate = 1;                 // JSORB_SPECULATE=0 / jsorb_set_speculative_stereo(l, 0) disable
     float *sp_u = nullptr, *sp_d = nullptr, *h_sp_u = nullptr, *h_sp_d = nullptr;   // twin output buffers (left handle), swapped in on adoption
+    const int *l1_view = nullptr;      // L1 distances of the last match: st_l1, or sp_l1 after an adopted speculative match (jsorb_copy_stereo_l1)
     int *sp_stats = nullptr, *h_sp_stats = nullptr, *sp_l1 = nullptr;   // sp_l1 / sp_aux: scratch of the speculative match (one pair)
     unsigned *sp_aux = nullptr;
     ImageSrc src{};            // where level 0 of the last extract lives
@@ -1364,6 +1365,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
         if (r->last_stage >= 0) r->consumed_K[r->last_stage] = l->K;
     }
     l->stereo_done = true;
+    l->l1_view = l->st_l1;
     l->st_mirror_valid = false;
     l->st_mirror_pending = direct;
     l->stereo_pairs = n;
@@ -1401,6 +1403,14 @@ int jsorb_copy_stereo(const jsorb_extractor *l, int image, float *u_right, float
         stats->n_final = s[3];
     }
     return JSORB_OK;
+}
+
+int jsorb_copy_stereo_l1(const jsorb_extractor *l, int image, int32_t *dst)
+{
+    if (!check_image(l, image) || !l->stereo_done || !dst || !l->l1_view) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(l, image);
+    if (n <= 0) return JSORB_OK;
+    return hipMemcpy(dst, l->l1_view + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
 }
 
 int jsorb_gather_counts_async(jsorb_extractor *l, jsorb_extractor *r, int32_t *dev_dst)
@@ -1445,6 +1455,7 @@ int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float m
         std::swap(l->st_u, l->sp_u); std::swap(l->st_d, l->sp_d); std::swap(l->st_stats, l->sp_stats);
         std::swap(l->h_u, l->h_sp_u); std::swap(l->h_d, l->h_sp_d); std::swap(l->h_stats, l->h_sp_stats);
         l->stereo_done = true;
+        l->l1_view = l->sp_l1;
         l->stereo_pairs = 1;
         l->st_mirror_valid = true;
         l->st_mirror_pending = false;

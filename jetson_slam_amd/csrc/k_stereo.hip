@@ -267,90 +267,6 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
 // 2.1 x median cut (orb_stereo_match.cu:563-578).  The median of the sorted (dist, idx) pairs is the (nv/2)-th smallest
 // distance; L1 distances are < 2^16 (121*510), so a two-pass 256-bin radix select in LDS finds it exactly.
 // generic form (any number of keypoints): three passes over the distances in memory, bin searches by thread 0
-__device__ __noinline__ void median_big(const Geometry &g, const int *__restrict__ countsL, float *__restrict__ u_right,
-                                                float *__restrict__ depth, const int *__restrict__ best_l1,
-                                                const unsigned *__restrict__ aux, int *__restrict__ stats, DeliverStereo dl)
-{
-    __shared__ int hist[256];
-    __shared__ int sel[4];
-    __shared__ int s_cand, s_corr, s_removed;
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
-    const size_t tb = (size_t)b * g.T;
-    int *st = stats + b * 8;
-    hist[tid] = 0;
-    if (tid == 0) { s_cand = 0; s_corr = 0; s_removed = 0; }
-    __syncthreads();
-    int cand = 0, corr = 0;
-    for (int i = tid; i < Nl; i += 256) {
-        const int d = best_l1[tb + i];
-        if (d >= 0) atomicAdd(&hist[(d >> 8) & 255], 1);
-        const unsigned a = aux[tb + i];
-        cand += (int)(a & 0x7FFFFFFFu);
-        corr += (int)(a >> 31);
-    }
-    cand = wave_sum_i32(cand);
-    corr = wave_sum_i32(corr);
-    if ((tid & 63) == 0) { atomicAdd(&s_cand, cand); atomicAdd(&s_corr, corr); }
-    __syncthreads();
-    if (tid == 0) {
-        int nv = 0;
-        for (int k = 0; k < 256; k++) nv += hist[k];
-        sel[2] = nv;
-        int kth = nv / 2, cum = 0, bin = 0;
-        for (int k = 0; k < 256; k++) {
-            if (cum + hist[k] > kth) { bin = k; break; }
-            cum += hist[k];
-        }
-        sel[0] = bin;
-        sel[1] = kth - cum;     // rank inside the bin
-    }
-    __syncthreads();
-    const int nv = sel[2];
-    float thDist = 3.0e38f;     // Appendix C-6: nothing matched -> no cut
-    if (nv > 0) {
-        const int bin = sel[0], kin = sel[1];
-        __syncthreads();
-        hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < Nl; i += 256) {
-            const int d = best_l1[tb + i];
-            if (d >= 0 && ((d >> 8) & 255) == bin) atomicAdd(&hist[d & 255], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int cum = 0, low = 0;
-            for (int k = 0; k < 256; k++) {
-                if (cum + hist[k] > kin) { low = k; break; }
-                cum += hist[k];
-            }
-            sel[3] = (bin << 8) | low;
-        }
-        __syncthreads();
-        const float median = (float)sel[3];
-        thDist = 1.5f * 1.4f * median;
-    }
-    int removed = 0;
-    for (int i = tid; i < Nl; i += 256) {
-        const int d = best_l1[tb + i];
-        float u = u_right[tb + i], z = depth[tb + i];
-        if (d >= 0 && !((float)d < thDist)) {
-            u = -1.0f; z = -1.0f;
-            u_right[tb + i] = u;
-            depth[tb + i] = z;
-            removed++;
-        }
-        if (dl.u_host) { dl.u_host[i] = u; dl.d_host[i] = z; }
-    }
-    if (removed) atomicAdd(&s_removed, removed);
-    __syncthreads();
-    if (tid == 0) {
-        const int v[4] = {s_cand, s_corr, nv, nv - s_removed};
-        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[b * 8 + k] = v[k]; }
-    }
-}
-
-// exclusive prefix of one value per thread over the 256 threads of the workgroup (s_w: 4 ints of LDS scratch); also returns the total
 __device__ __forceinline__ int block256_exclusive_scan(int v, int *s_w, int &total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -364,28 +280,117 @@ __device__ __forceinline__ int block256_exclusive_scan(int v, int *s_w, int &tot
     return base + incl - v;
 }
 
-// Same result as k_median_big for pairs with at most 256 * MED_R left keypoints: the L1 distances stay in registers over the three
-// passes and the two bin searches are workgroup prefix scans instead of 256-step loops of one thread (the kernel is one
-// workgroup per pair and pure latency: 18 us -> a few us per launch).
+// The (nv/2)-th smallest L1 distance by two histogram passes: bin of the high byte, then of the low byte inside that bin.  An L1 distance
+// is a sum of 121 terms |(L - L_centre) - (R - R_centre)| <= 510, i.e. < 2^16.  The distances of a pair cluster in a few bins, where LDS
+// atomics on one address serialise, so every wave adds into its own copy of the histogram (4 x 256 counters).
+#define MED_BIN_SHIFT 8
+static_assert((2 * 5 + 1) * (2 * 5 + 1) * 510 < (256 << MED_BIN_SHIFT), "L1 distance range exceeds the first-level histogram");
+
+struct MedianShared {
+    int hist[4][256];
+    int sel[4];
+    int s_w[4];
+    int s_cand, s_corr, s_removed;
+};
+
+// VALUES(fn): calls fn(d, r) for every distance slot of this thread (d < 0: no match); the register-resident and the re-reading form
+// share everything else.
+template <class ForEach>
+__device__ __forceinline__ float median_threshold(MedianShared &sm, int tid, ForEach for_each, int &nv_out)
+{
+    const int wave = tid >> 6;
+    for_each([&](int d) { if (d >= 0) atomicAdd(&sm.hist[wave][d >> MED_BIN_SHIFT], 1); });
+    __syncthreads();
+    int nv;
+    {
+        const int h = sm.hist[0][tid] + sm.hist[1][tid] + sm.hist[2][tid] + sm.hist[3][tid];
+        const int excl = block256_exclusive_scan(h, sm.s_w, nv);
+        const int kth = nv / 2;
+        if (h > 0 && excl <= kth && kth < excl + h) { sm.sel[0] = tid; sm.sel[1] = kth - excl; }      // exactly one bin (nv > 0)
+    }
+    nv_out = nv;
+    if (nv == 0) return 3.0e38f;                       // Appendix C-6: nothing matched -> no cut (nv is workgroup-uniform)
+    __syncthreads();                                   // everybody has read the first-level counters
+#pragma unroll
+    for (int w = 0; w < 4; w++) sm.hist[w][tid] = 0;
+    __syncthreads();
+    const int bin = sm.sel[0], kin = sm.sel[1];
+    for_each([&](int d) { if (d >= 0 && (d >> MED_BIN_SHIFT) == bin) atomicAdd(&sm.hist[wave][d & ((1 << MED_BIN_SHIFT) - 1)], 1); });
+    __syncthreads();
+    {
+        const int h = sm.hist[0][tid] + sm.hist[1][tid] + sm.hist[2][tid] + sm.hist[3][tid];
+        int tot;
+        const int excl = block256_exclusive_scan(h, sm.s_w, tot);
+        if (h > 0 && excl <= kin && kin < excl + h) sm.sel[3] = (bin << MED_BIN_SHIFT) | tid;
+    }
+    __syncthreads();
+    const float median = (float)sm.sel[3];
+    return 1.5f * 1.4f * median;
+}
+
+// Pairs with more left keypoints than the register-resident form holds: the distances are re-read from global memory (L2 hits) in
+// each of the three passes.
+__device__ __noinline__ void median_big(MedianShared &sm, const Geometry &g, const int *__restrict__ countsL, float *__restrict__ u_right,
+                                        float *__restrict__ depth, const int *__restrict__ best_l1,
+                                        const unsigned *__restrict__ aux, int *__restrict__ stats, DeliverStereo dl)
+{
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
+    const size_t tb = (size_t)b * g.T;
+    int *st = stats + b * 8;
+    int cand = 0, corr = 0;
+    for (int i = tid; i < Nl; i += 256) {
+        const unsigned a = aux[tb + i];
+        cand += (int)(a & 0x7FFFFFFFu);
+        corr += (int)(a >> 31);
+    }
+    cand = wave_sum_i32(cand);
+    corr = wave_sum_i32(corr);
+    if ((tid & 63) == 0) { atomicAdd(&sm.s_cand, cand); atomicAdd(&sm.s_corr, corr); }
+    int nv;
+    const float thDist = median_threshold(sm, tid, [&](auto f) { for (int i = tid; i < Nl; i += 256) f(best_l1[tb + i]); }, nv);
+    int removed = 0;
+    for (int i = tid; i < Nl; i += 256) {
+        const int d = best_l1[tb + i];
+        float u = u_right[tb + i], z = depth[tb + i];
+        if (d >= 0 && !((float)d < thDist)) {
+            u = -1.0f; z = -1.0f;
+            u_right[tb + i] = u;
+            depth[tb + i] = z;
+            removed++;
+        }
+        if (dl.u_host) { dl.u_host[i] = u; dl.d_host[i] = z; }
+    }
+    if (removed) atomicAdd(&sm.s_removed, removed);
+    __syncthreads();
+    if (tid == 0) {
+        const int v[4] = {sm.s_cand, sm.s_corr, nv, nv - sm.s_removed};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[b * 8 + k] = v[k]; }
+    }
+}
+
+// Median cut of one stereo pair per workgroup (orb_stereo_match.cu:560-580: sort, median = dist[size/2], thDist = 1.5*1.4*median, matches
+// with dist >= thDist lose uRight / depth) + the per-pair statistics.  Pairs with at most 256 * MED_R left keypoints keep their L1
+// distances in registers over the three passes.
 #define MED_R 32
 __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restrict__ countsL, float *__restrict__ u_right,
                                                 float *__restrict__ depth, const int *__restrict__ best_l1,
                                                 const unsigned *__restrict__ aux, int *__restrict__ stats, DeliverStereo dl)
 {
-    __shared__ int hist[256];
-    __shared__ int sel[4];
-    __shared__ int s_w[4];
-    __shared__ int s_cand, s_corr, s_removed;
+    __shared__ MedianShared sm;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int Nl = countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS];
     const size_t tb = (size_t)b * g.T;
     int *st = stats + b * 8;
-    if (Nl > 256 * MED_R) {                                // wave-uniform: too many keypoints for the register-resident form
-        median_big(g, countsL, u_right, depth, best_l1, aux, stats, dl);
+#pragma unroll
+    for (int w = 0; w < 4; w++) sm.hist[w][tid] = 0;
+    if (tid == 0) { sm.s_cand = 0; sm.s_corr = 0; sm.s_removed = 0; }
+    __syncthreads();
+    if (Nl > 256 * MED_R) {                                // workgroup-uniform: too many keypoints for the register-resident form
+        median_big(sm, g, countsL, u_right, depth, best_l1, aux, stats, dl);
         return;
     }
-    hist[tid] = 0;
-    if (tid == 0) { s_cand = 0; s_corr = 0; s_removed = 0; }
     int d[MED_R];
     int cand = 0, corr = 0;
 #pragma unroll
@@ -399,41 +404,14 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
             corr += (int)(a >> 31);
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < MED_R; r++)
-        if (d[r] >= 0) atomicAdd(&hist[(d[r] >> 8) & 255], 1);
     cand = wave_sum_i32(cand);
     corr = wave_sum_i32(corr);
-    if ((tid & 63) == 0) { atomicAdd(&s_cand, cand); atomicAdd(&s_corr, corr); }
-    __syncthreads();
-    // the (nv/2)-th smallest distance: bin of the high byte, then of the low byte inside that bin
+    if ((tid & 63) == 0) { atomicAdd(&sm.s_cand, cand); atomicAdd(&sm.s_corr, corr); }
     int nv;
-    {
-        const int h = hist[tid];
-        const int excl = block256_exclusive_scan(h, s_w, nv);
-        const int kth = nv / 2;
-        if (h > 0 && excl <= kth && kth < excl + h) { sel[0] = tid; sel[1] = kth - excl; }      // exactly one bin (nv > 0)
-    }
-    float thDist = 3.0e38f;     // Appendix C-6: nothing matched -> no cut (nv is workgroup-uniform)
-    if (nv > 0) {
-        hist[tid] = 0;
-        __syncthreads();
-        const int bin = sel[0], kin = sel[1];
+    const float thDist = median_threshold(sm, tid, [&](auto f) {
 #pragma unroll
-        for (int r = 0; r < MED_R; r++)
-            if (d[r] >= 0 && ((d[r] >> 8) & 255) == bin) atomicAdd(&hist[d[r] & 255], 1);
-        __syncthreads();
-        {
-            const int h = hist[tid];
-            int tot;
-            const int excl = block256_exclusive_scan(h, s_w, tot);
-            if (h > 0 && excl <= kin && kin < excl + h) sel[3] = (bin << 8) | tid;
-        }
-        __syncthreads();
-        const float median = (float)sel[3];
-        thDist = 1.5f * 1.4f * median;
-    }
+        for (int r = 0; r < MED_R; r++) f(d[r]);
+    }, nv);
     int removed = 0;
     if (dl.u_host) {            // single-pair call: the final uRight / depth also go to the pinned host mirror
 #pragma unroll 4
@@ -462,10 +440,10 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
             }
         }
     }
-    if (removed) atomicAdd(&s_removed, removed);
+    if (removed) atomicAdd(&sm.s_removed, removed);
     __syncthreads();
     if (tid == 0) {
-        const int v[4] = {s_cand, s_corr, nv, nv - s_removed};
+        const int v[4] = {sm.s_cand, sm.s_corr, nv, nv - sm.s_removed};
 #pragma unroll
         for (int k = 0; k < 4; k++) { st[k] = v[k]; if (dl.stats_host) dl.stats_host[b * 8 + k] = v[k]; }
     }

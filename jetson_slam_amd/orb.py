@@ -31,7 +31,7 @@ EXPORTS = [
     "jsorb_copy_descriptors", "jsorb_n_levels", "jsorb_level_dims", "jsorb_level_tiles", "jsorb_total_tiles", "jsorb_scale",
     "jsorb_inv_scale", "jsorb_level_image_device", "jsorb_copy_level_image", "jsorb_copy_tile_candidates", "jsorb_copy_angles",
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
-    "jsorb_copy_stereo", "jsorb_set_speculative_stereo", "jsorb_speculative_stereo_stats", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
+    "jsorb_copy_stereo", "jsorb_copy_stereo_l1", "jsorb_set_speculative_stereo", "jsorb_speculative_stereo_stats", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
     "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
     "jsorb_unpack_frame", "jsorb_assign_features_to_grid", "jsorb_copy_level_mask",
     "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
@@ -111,6 +111,7 @@ def load_library(path=None):
         "jsorb_stereo_depth_device": (P, [P, I]),
         "jsorb_copy_stereo": (I, [P, I, P, P, C.POINTER(JsorbStereoStats)]),
         "jsorb_gather_counts_async": (I, [P, P, P]),
+        "jsorb_copy_stereo_l1": (I, [P, I, P]),
         "jsorb_set_speculative_stereo": (I, [P, I]),
         "jsorb_speculative_stereo_stats": (I, [P, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "jsorb_set_stream": (I, [P, P]),
@@ -406,6 +407,14 @@ def stereo_result(left, image=0):
     st = JsorbStereoStats()
     left._chk(left._lib.jsorb_copy_stereo(left.handle, image, u.ctypes.data, d.ctypes.data, C.byref(st)))
     return u[:n], d[:n], {k: getattr(st, k) for k, _ in JsorbStereoStats._fields_}
+
+
+def stereo_l1(left, image=0):
+    """L1 distances the median cut sorted (-1 = no accepted refinement), int32[N_left]"""
+    n = left.n_keypoints(image)
+    out = np.full(max(n, 1), -1, np.int32)
+    left._chk(left._lib.jsorb_copy_stereo_l1(left.handle, image, out.ctypes.data))
+    return out[:n]
 
 
 def gather_counts_async(left, right, dev_dst_ptr):

@@ -53,6 +53,7 @@ def _load(native=False):
         "orc_tile_score": (C.POINTER(C.c_int32), [P]),
         "orc_stereo_best_right": (C.POINTER(C.c_int32), [P]),
         "orc_stereo_best_dist": (C.POINTER(C.c_int32), [P]),
+        "orc_stereo_l1": (C.POINTER(C.c_int32), [P]),
         "orc_atan2f": (C.c_float, [C.c_float, C.c_float]),
         "orc_cosf": (C.c_float, [C.c_float]),
         "orc_sinf": (C.c_float, [C.c_float]),
@@ -216,6 +217,7 @@ def stereo_match(left, right, mb, mbf, th_high=100, th_low=50):
     stats = {k: getattr(st, k) for k, _ in OrcStereoStats._fields_}
     stats["best_right"] = _arr(left.l.orc_stereo_best_right(left.h), n, np.int32)
     stats["best_dist"] = _arr(left.l.orc_stereo_best_dist(left.h), n, np.int32)
+    stats["l1"] = _arr(left.l.orc_stereo_l1(left.h), n, np.int32)
     return u[:n], d[:n], stats
 
 

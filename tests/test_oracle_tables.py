@@ -137,3 +137,19 @@ def test_mask_pyramid_uses_opencv_resize_nn_indices(po):
             sy, sx = _opencv_resize_nn_index(h, H), _opencv_resize_nn_index(w, W)
             want = np.where(mask[sy][:, sx] > 10, 255, 0).astype(np.uint8)
             assert np.array_equal(o.level_mask(lv), want), (H, W, lv)
+
+
+def test_l1_distances_of_the_median_cut_exceed_15_bits_on_a_pinned_pair(po):
+    """The L1 window distance is a sum of 121 terms |(L - L_centre) - (R - R_centre)| <= 510: it does not fit 15 bits.  Seed 29 of the
+    KITTI-shaped configuration has a match above 32767 (the GPU test of the same pair relies on it: a histogram of the median cut that
+    assumed 15 bits passed every other test of the suite)."""
+    from jetson_slam_amd.synth import synth_stereo_pair
+    c = dict(h=376, w=1241, L=8, tile=25, th=60, fx=718.86, bf=386.14)
+    kw = dict(height=c["h"], width=c["w"], n_levels=c["L"], tile_h=c["tile"], tile_w=c["tile"], fast_n_min=9, fast_n_max=14, th_fast_max=c["th"])
+    a, b = po.OracleExtractor(**kw), po.OracleExtractor(**kw)
+    l, r = synth_stereo_pair(29, c["h"], c["w"])
+    a.extract(l); b.extract(r)
+    u, d, st = po.stereo_match(a, b, c["bf"] / c["fx"], c["bf"])
+    l1 = st["l1"]
+    assert l1.shape[0] == a.n and (l1 >= 0).sum() == st["n_depth"] and l1.max() >= 32768 and l1.max() < 121 * 510
+    assert ((l1 >= 0) & (d > 0)).sum() == st["n_final"] and np.all(d[l1 < 0] == -1)
