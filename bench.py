@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--pairs-total", type=int, default=0, help="strong scaling: this many pairs per step over ALL GPUs (64 on c2 = BASELINE C4)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--min-time", type=float, default=2.0, help="repeat the block of --steps steps until this many seconds are measured; the median block is reported")
+    ap.add_argument("--seed-base", type=int, default=1, help="seed of the first synthetic pair (parity soaks over other pairs: tools/micro/soak_bench.sh)")
     ap.add_argument("--unique", type=int, default=0, help="unique synthetic pairs per rank (default: one per pair of the step, at most 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-streamed / frame-latency / C4 side measurements")
@@ -184,7 +185,7 @@ def main():
     # step is a different image pair (up to 128 unique per rank)
     n_unique = args.unique if args.unique > 0 else min(P, 128)
     n_unique = max(1, min(n_unique, P))
-    host_pairs = [synth_stereo_pair(1 + rank * 1000 + i, H, W) for i in range(n_unique)]
+    host_pairs = [synth_stereo_pair(args.seed_base + rank * 1000 + i, H, W) for i in range(n_unique)]
     left_u = np.stack([p[0] for p in host_pairs])
     right_u = np.stack([p[1] for p in host_pairs])
     idx = np.arange(P) % n_unique
