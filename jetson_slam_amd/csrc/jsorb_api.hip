@@ -139,7 +139,13 @@ struct jsorb_extractor {
     // the 5-kernel chain of a single image as a HIP graph (captured on first use, replayed while the arguments stay the same): one
     // hipGraphLaunch instead of five kernel launches on the host's critical path (JSORB_FRAME_GRAPH=0 disables)
     hipGraphExec_t frame_graph = nullptr;
-    const void *fg_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // l0 source, its pitch, main stream, the two caller-owned destinations
+    const void *fg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // l0 source, its pitch, main stream, the two caller-owned destinations, upload node
+    // single frame from pageable host memory: the calling thread copies the image into this pinned buffer and the first kernel of the
+    // frame pulls it over PCIe (JSORB_KERNEL_UPLOAD=0: hipMemcpyAsync instead).  hipMemcpyAsync from pageable memory goes through a
+    // staging buffer of the runtime that the two extractor threads of a stereo frame take turns on: the right image started ~20 us late.
+    uint8_t *h_upload = nullptr;
+    int kernel_upload = 1;
+    bool upload_pending = false;       // transient: run_pipeline starts the single-image chain with the upload kernel
     int fg_recaptures = 0;             // consecutive frames whose arguments differed from the captured ones
     int use_frame_graph = 1;
     int32_t *deliver_kp_dev = nullptr;      // jsorb_extract_into: caller-owned device destinations of the next single-image pipeline
@@ -538,7 +544,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         // single image on an untimed handle: replay the captured graph of the five launches when nothing they depend on has changed
         bool capturing = false;
         if (direct && e->use_frame_graph && !e->timing && !e->nms_ms) {
-            const void *key[5] = {e->src.l0, (const void *)(uintptr_t)e->src.l0_pitch, st, e->deliver_kp_dev, e->deliver_desc_dev};
+            const void *key[6] = {e->src.l0, (const void *)(uintptr_t)e->src.l0_pitch, st, e->deliver_kp_dev, e->deliver_desc_dev, e->upload_pending ? e->h_upload : nullptr};
             if (e->frame_graph && memcmp(key, e->fg_key, sizeof key) == 0) {
                 e->fg_recaptures = 0;
                 HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
@@ -562,6 +568,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
             if (e->stagger && j + 1 < K) HIPCHK(e, hipEventRecord(e->ev_stage[j][stage], st));                              \
             stage++;                                                                                                        \
         } while (0)
+        if (e->upload_pending) launch_upload_level0(e->h_upload, e->stage[0], (size_t)g.lv[0].H * g.lv[0].W, st);
         JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
         JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
         if (e->nms_ms)
@@ -585,6 +592,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
     }
     e->copy_kind = 0;
+    e->upload_pending = false;
     e->mirror_pending = direct;
     e->deliver_kp_dev = nullptr;
     e->deliver_desc_dev = nullptr;
@@ -751,6 +759,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
     if (const char *sw = getenv("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
     if (const char *sp = getenv("JSORB_SPECULATE")) e->speculate = atoi(sp);
+    if (const char *ku = getenv("JSORB_KERNEL_UPLOAD")) e->kernel_upload = atoi(ku);
     if (const char *hl = getenv("JSORB_HOST_LANES")) e->host_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(hl)));
     if (const char *tr = getenv("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
     if (const char *fg = getenv("JSORB_FRAME_GRAPH")) e->use_frame_graph = atoi(fg);
@@ -894,7 +903,7 @@ void jsorb_destroy(jsorb_extractor *e)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
-    for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d, (void *)e->h_sp_u, (void *)e->h_sp_d, (void *)e->h_sp_stats})
+    for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d, (void *)e->h_sp_u, (void *)e->h_sp_d, (void *)e->h_sp_stats, (void *)e->h_upload})
         if (hp) (void)hipHostFree(hp);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -993,6 +1002,8 @@ static int mark_buffer_consumed(jsorb_extractor *e, int k)
     return JSORB_OK;
 }
 
+static int wait_event(jsorb_extractor *e, hipEvent_t ev, bool spin);
+
 // *mark: the landing buffer whose "consumed" events the caller records after everything else it enqueues for this call (-1: none)
 static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images, int *mark)
 {
@@ -1006,7 +1017,16 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         if ((rc = wait_buffer_consumed(e, 0, e->stream))) return rc;
         if ((rc = join_previous_on_main(e))) return rc;
         const double t0 = e->trace_host ? now_us() : 0.0;
-        HIPCHK(e, hipMemcpyAsync(e->stage[0], host_images, img_bytes, hipMemcpyHostToDevice, e->stream));
+        if (e->kernel_upload) {
+            if (!e->h_upload) HIPCHK(e, hipHostMalloc(&e->h_upload, img_bytes));
+            // the previous frame's upload kernel has read the pinned buffer when that frame's kernels are done (asynchronous callers
+            // that have not waited for it yet wait here)
+            if (e->mirror_pending && (rc = wait_event(e, e->lane_done[0], e->spin_wait != 0))) return rc;
+            memcpy(e->h_upload, host_images, img_bytes);
+            e->upload_pending = true;
+        } else {
+            HIPCHK(e, hipMemcpyAsync(e->stage[0], host_images, img_bytes, hipMemcpyHostToDevice, e->stream));
+        }
         const double t1 = e->trace_host ? now_us() : 0.0;
         e->src.l0 = e->stage[0]; e->src.l0_stride = img_bytes; e->src.l0_pitch = l0.W;
         if ((rc = run_pipeline(e, n_images))) return rc;
