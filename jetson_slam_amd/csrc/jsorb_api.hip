@@ -105,7 +105,7 @@ struct jsorb_extractor {
     // host uploads: two dense B x H0 x W0 landing buffers filled by ONE hipMemcpyAsync per batch on a dedicated copy stream, then read
     // in place as level 0.  Double buffering lets the upload of batch k+1 overlap the kernels of batch k.
     uint8_t *stage[2] = {nullptr, nullptr};
-    int host_lanes = 2;                     // cap on the lanes of a host-uploaded batch (JSORB_HOST_LANES): PCIe-bound, see extract_batch_host_enqueue
+    int host_lanes = 1;                     // cap on the lanes of a host-uploaded batch (JSORB_HOST_LANES): PCIe-bound, see extract_batch_host_enqueue
     int lane_cap = JSORB_MAX_LANES;         // transient: cap for the batch being enqueued
     hipEvent_t ev_copied[2][JSORB_MAX_LANES] = {};   // per landing buffer and lane: the lane's images have arrived
     int consumed_n[2] = {0, 0};        // images of the batch that last used the buffer (with consumed_K: its lane partition)
@@ -1041,9 +1041,10 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         // The upload is cut at the lane boundaries of the batch: lane j starts as soon as ITS images have landed, and its part of the
         // buffer is refilled as soon as lane j of the batch that used the buffer two batches ago (extract kernels and, if any, the
         // stereo match) has finished - the copy engine never waits for a whole batch.
-        // At most two lanes: the regime is PCIe-bound (a pair is 722 kB; 57 GB/s = 79 k pairs/s against 91 k for the kernels), so the
-        // kernels do not need the overlap of 4 lanes, and coarser chunks measured better (8 hardware queues, 128 / 256 pairs per batch:
-        // 2 lanes 65 / 74 k, 3 lanes 59 / 65 k, 4 lanes 48 / 58 k pairs/s).
+        // One lane: the regime is PCIe-bound (a pair is 722 kB; 57 GB/s = 79 k pairs/s against 85 k for the kernels on one lane), so the
+        // kernels do not need the overlap of several lanes, and one upload per handle and batch runs at the full rate of the link where
+        // lane-sized chunks reach 49-51 GB/s with 18-24 us between them (measured at 64 / 128 / 256 pairs per batch on 16 hardware
+        // queues: 1 lane 60.6 / 70.2 / 73.1 k, 2 lanes 55.5 / 62.4 / 69.9 k, 4 lanes 48 / 58 k pairs/s).  JSORB_HOST_LANES raises the cap.
         const int k = e->stage_cur;
         int first[JSORB_MAX_LANES + 1];
         e->lane_cap = e->host_lanes;
