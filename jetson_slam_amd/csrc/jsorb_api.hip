@@ -1036,11 +1036,11 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         return JSORB_OK;
     }
     if (e->stage[0] && step == l0.W && image_stride == img_bytes) {
-        // dense batch: ONE pinned hipMemcpyAsync for all images on the copy stream, then level 0 is read in place from the landing
-        // buffer.  The buffer being refilled was last read two batches ago (its extract kernels and, if any, the stereo match).
-        // The upload is cut at the lane boundaries of the batch: lane j starts as soon as ITS images have landed, and its part of the
-        // buffer is refilled as soon as lane j of the batch that used the buffer two batches ago (extract kernels and, if any, the
-        // stereo match) has finished - the copy engine never waits for a whole batch.
+        // dense batch: pinned hipMemcpyAsync on the device's upload stream into a landing buffer, then level 0 is read in place from
+        // there.  The buffer being refilled was last read two batches ago (its extract kernels and, if any, the stereo match), so the
+        // upload of batch k+1 runs under the kernels of batch k.  With more than one lane (JSORB_HOST_LANES) the upload is cut at the
+        // lane boundaries: lane j starts as soon as ITS images have landed and its part of the buffer is refilled as soon as lane j of
+        // the batch that used it has finished.
         // One lane: the regime is PCIe-bound (a pair is 722 kB; 57 GB/s = 79 k pairs/s against 85 k for the kernels on one lane), so the
         // kernels do not need the overlap of several lanes, and one upload per handle and batch runs at the full rate of the link where
         // lane-sized chunks reach 49-51 GB/s with 18-24 us between them (measured at 64 / 128 / 256 pairs per batch on 16 hardware
