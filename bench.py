@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--pairs-total", type=int, default=0, help="strong scaling: this many pairs per step over ALL GPUs (64 on c2 = BASELINE C4)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--min-time", type=float, default=2.0, help="repeat the block of --steps steps until this many seconds are measured; the median block is reported")
+    ap.add_argument("--tile", type=int, default=0, help="override the configuration's tile size (default: the yaml-faithful one)")
     ap.add_argument("--seed-base", type=int, default=1, help="seed of the first synthetic pair (parity soaks over other pairs: tools/micro/soak_bench.sh)")
     ap.add_argument("--unique", type=int, default=0, help="unique synthetic pairs per rank (default: one per pair of the step, at most 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,6 +174,8 @@ def main():
     gloo = world > 1 and os.environ.get("JSORB_BENCH_BACKEND", "nccl") != "nccl"
 
     cfg = CONFIGS[args.config]
+    if args.tile > 0:           # the "nominal feature count" variants of SURVEY 8(d): c2 tile 58 (cap 999), c3 tile 46 (cap 2016), c5 tile 52 (cap 2920)
+        cfg = (cfg[0], cfg[1], cfg[2], args.tile) + tuple(cfg[4:])
     H, W, L, tile, th, fx, bf = cfg
     strong = args.pairs_total > 0
     if strong:
@@ -408,7 +411,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8/int32 (+f32 orientation/blur)",
             "data": "synthetic",
-            "config": {"workload": WORKLOAD_NAMES[args.config] + (" (cap %d kp/image)" % T) +
+            "config": {"workload": WORKLOAD_NAMES[args.config] + (" [tile overridden: %d]" % args.tile if args.tile > 0 else "") + (" (cap %d kp/image)" % T) +
                                    ("; BASELINE C4: %d pairs per step sharded over %d GPU(s)" % (args.pairs_total, world) if strong else ""),
                        "name": args.config, "pairs_per_gpu_per_step": P, "pairs_per_step_total": P * world, "unique_pairs_per_gpu": n_unique,
                        "handle_pairs": G, "library_lanes": "up to 4 HIP streams per handle (>= ~7 Mpx per lane)", "keypoints_image0": n0,
