@@ -89,7 +89,12 @@ int jsorb_extract_device(jsorb_extractor *e, const uint8_t *dev_image, int step,
 /* Batch mode: n_images (<= max_batch) images at dev_images + i*image_stride, rows `step` bytes apart.  Enqueues only; the
  * input buffer must stay valid until jsorb_sync (level 0 is read in place).  Results per image via the accessors below. */
 int jsorb_extract_batch_device_async(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images);
-/* Batch mode from pinned/pageable host memory: hipMemcpy2DAsync into the level-0 slab, then the same kernels. */
+/* Batch mode from host memory (pinned for asynchronous uploads; pageable works, the copy then blocks the caller).  Dense input
+ * (image_stride == H*W, step == W, W a multiple of 16): one hipMemcpyAsync per batch on the device's upload stream into one of two
+ * landing buffers that the kernels read in place, so that the upload of batch k+1 runs under the kernels of batch k; the host buffer may
+ * be reused once the upload has run (jsorb_sync, or any later call that returned after it).  One image (n_images == 1) from any host
+ * memory: copied into a pinned buffer of the handle by the calling thread and pulled over PCIe by the first kernel.  Strided input:
+ * hipMemcpy2DAsync per image into the level-0 slab. */
 int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_images, size_t image_stride, int step, int n_images);
 /* Wait for everything enqueued on this handle and refresh the host-side counts. */
 int jsorb_sync(jsorb_extractor *e);
