@@ -1,5 +1,5 @@
-// Probe: do external event record / wait nodes work inside a captured HIP graph on this runtime?  (ROCm 7.2.0 image: segmentation fault
-// inside the runtime during capture - which is why the speculative stereo match cannot be made part of the frame graph.)
+// Probe: do external event record / wait nodes work inside a captured HIP graph on this runtime?  (ROCm 7.2.0 image: the external
+// event RECORD is captured, hipStreamWaitEvent(..., hipEventWaitExternal) on the capturing stream segfaults inside the runtime - which is why the speculative stereo match cannot be made part of the frame graph.)
 // Build: hipcc --offload-arch=gfx950 -O2 -o tools/micro/graph_event_probe tools/micro/graph_event_probe.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -16,11 +16,16 @@ int main()
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, s, d, 2000);
+    printf("capture: kernel 1 ok\n"); fflush(stdout);
     CK(hipEventRecordWithFlags(mid, s, hipEventRecordExternal));
+    printf("capture: external event record ok\n"); fflush(stdout);
     CK(hipStreamWaitEvent(s, ext, hipEventWaitExternal));
+    printf("capture: external event wait ok\n"); fflush(stdout);
     hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, s, d, 2000);
     CK(hipStreamEndCapture(s, &g));
+    printf("capture ended\n"); fflush(stdout);
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    printf("instantiated\n"); fflush(stdout);
     size_t nn = 0; CK(hipGraphGetNodes(g, nullptr, &nn)); printf("graph nodes: %zu\n", nn);
     for (int rep = 0; rep < 5; rep++) {
         hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, other, d, rep == 4 ? 200000 : 2000);      // last repetition: the external event fires late
