@@ -252,17 +252,13 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         if (lv.blur_bx == 0 || lv.blur_by == 0) { lv.blur_bx = 1; lv.blur_by = 0; }
         lv.blur_blk0 = bblk;
         bblk += lv.blur_bx * lv.blur_by;
-        lv.pyr_bx = (lv.W + PYR_TW - 1) / PYR_TW; // k_pyramid: PYR_TW x PYR_TH output tile per workgroup
-        lv.pyr_blk0 = pblk;
-        // 16 output rows per workgroup while their level-0 window stays small; the high levels fall back to 8 so that the
-        // launch-wide LDS size (the maximum over the levels) keeps 8 workgroups per CU (k_pyramid is occupancy sensitive)
-        lv.pyr_th = pyramid_window_bytes(lv.pyr_s, PYR_TH) <= 12 * 1024 ? PYR_TH : 8;
-        if (i >= 1) pblk += lv.pyr_bx * ((lv.H + lv.pyr_th - 1) / lv.pyr_th);
     }
+    (void)pblk;
     g.T = tiles;
     if (tiles >= (1 << 20)) { err = "too many tiles"; return JSORB_ERR_INVALID; }
-    g.detect_blocks = dblk; g.blur_blocks = bblk; g.pyr_blocks = pblk; g.row_tab_len = rtab;
+    g.detect_blocks = dblk; g.blur_blocks = bblk; g.row_tab_len = rtab;
     g.slab_bytes = off;
+    fill_pyramid_layout(g);              // k_pyramid: PYR_TW x pyr_th output tile per (single-wave) workgroup
     return JSORB_OK;
 }
 
@@ -772,7 +768,8 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
     e->pyr_lds = pyramid_lds_bytes(g);
-    if (e->pyr_lds > 160 * 1024) { e->err = "pyramid scale too large for the LDS-staged resampler"; return JSORB_ERR_INVALID; }
+    for (int i = 1; i < g.L; i++)
+        if (g.lv[i].pyr_ns16 > 4) { e->err = "pyramid scale too large for the resampler (level scale must stay below 19)"; return JSORB_ERR_INVALID; }
     const size_t B = (size_t)e->B, T = (size_t)g.T;
     const size_t slab_total = B * g.slab_bytes + 4096;
     HIPCHK(e, hipMalloc(&e->slab, slab_total));

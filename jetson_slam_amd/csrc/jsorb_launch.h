@@ -20,7 +20,8 @@ struct StereoArgs {
 size_t detect_lds_bytes(const Geometry &g);
 
 size_t pyramid_lds_bytes(const Geometry &g);
-size_t pyramid_window_bytes(float s, int rows_out);      // LDS bytes of the level-0 window of one k_pyramid tile
+int pyramid_loads_per_row(float s);        // 16-byte loads per lane and level-0 row in k_pyramid
+void fill_pyramid_layout(Geometry &g);     // rows per k_pyramid tile (pyr_th), sparse windows, workgroup table offsets (host side, once per handle)
 void launch_upload_level0(const uint8_t *host_pinned, uint8_t *dst, size_t bytes, hipStream_t s);      // bytes: a multiple of 16
 void launch_copy_level0(const uint8_t *src, size_t image_stride, int step, uint8_t *slab, size_t slab_bytes, int pitch, int W, int H, int n_images, hipStream_t s);
 void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, const uint32_t *ctab, int n_images, size_t lds_bytes, hipStream_t s);
