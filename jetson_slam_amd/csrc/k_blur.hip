@@ -49,11 +49,13 @@ __constant__ unsigned c_gauss_bits[7][4] = {
 //   |C - S| <= gamma_49 * 255 * sum(w)                          = 7.45e-4      (gamma_n = n u / (1 - n u), u = 2^-24)
 //   |A - S| <= rounding of the two 7-FMA stages + 255 * sum |gv[j] gh[k] - w[j][k]|  = 2.13e-4 + 0.9e-5
 // (tests/test_blur_certificate.py recomputes both from the tables with exact rational arithmetic), hence |A - C| <= 9.7e-4.
-// A pixel whose A is farther than BLUR_DELTA = 2e-3 from an integer boundary therefore has floor(C) = floor(A) - decided with two
-// magic-number roundings; the others (~0.4 % of natural pixels; every pixel of an exactly flat window, whose C lies within 1e-4 of an
-// integer) are listed per workgroup and recomputed with the exact chain; a tile with too many of them is recomputed densely by the
-// exact strip code.  The output is bit-identical to the chain in every case.
-#define BLUR_DELTA 2.0e-3f
+// A pixel whose A is farther than BLUR_BAND = 2^-8 = 3.9e-3 from an integer therefore has floor(C) = floor(A) - decided with ONE
+// magic-number addition rounded down (round 3; two roundings, two clamps and two subtractions per pixel pair before): floor(256 A)
+// lands in the mantissa, its high byte is the result and a low byte of 0 or 255 marks the pixel as undecided.  Those (~0.8 % of
+// natural pixels; every pixel of an exactly flat window, whose C lies within 1e-4 of an integer) are listed per workgroup and
+// recomputed with the exact chain; a tile with too many of them is recomputed densely by the exact strip code.  The output is
+// bit-identical to the chain in every case.
+#define BLUR_BAND 0.00390625f
 #define BLUR_AMB_CAP 1024      // listed ambiguous pixels per workgroup (of 8192) before the dense exact path takes over
 
 // separable factors: gv[j] = exp(-j^2/200) and gh[k] = exp(-k^2/200) / 47.092777252197266 (the reference's f32 weight sum 0x423C5F01),
@@ -173,39 +175,49 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
         }
         // horizontal stage + certificate, pixel pair (j, j + 8) at a time
         const f2 gh2[4] = {(f2){c_sep_h[0], c_sep_h[0]}, (f2){c_sep_h[1], c_sep_h[1]}, (f2){c_sep_h[2], c_sep_h[2]}, (f2){c_sep_h[3], c_sep_h[3]}};
-        const f2 zlo = (f2){-0.5f - BLUR_DELTA, -0.5f - BLUR_DELTA}, zhi = (f2){-0.5f + BLUR_DELTA, -0.5f + BLUR_DELTA};
-        const f2 magic = (f2){12582912.0f, 12582912.0f};
+        const f2 magic = (f2){49152.0f, 49152.0f};
         unsigned ow[BLUR_ROWS][BLUR_STRIP / 4];
-        unsigned amb = 0;                              // bit 16 o + p: pixel p of output row o needs the exact chain
+        unsigned amb = 0;                              // undecided pixels: byte t, bit 7 - k  <=>  pixel 4 (k & 3) + t of output row k >> 2
 #pragma unroll
         for (int o = 0; o < BLUR_ROWS; o++) {
+            f2 h[BLUR_HALF];
 #pragma unroll
-            for (int jg = 0; jg < BLUR_HALF; jg += 4) {
-                unsigned lo4[4], hi4[4];               // rounded values of pixels jg .. jg+3 and jg+8 .. jg+11 (low byte = the result)
+            for (int j = 0; j < BLUR_HALF; j++) {
+                f2 t = gh2[3] * VA[o][j];
+                t = __builtin_elementwise_fma(gh2[2], VA[o][j + 1], t);
+                t = __builtin_elementwise_fma(gh2[1], VA[o][j + 2], t);
+                t = __builtin_elementwise_fma(gh2[0], VA[o][j + 3], t);
+                t = __builtin_elementwise_fma(gh2[1], VA[o][j + 4], t);
+                t = __builtin_elementwise_fma(gh2[2], VA[o][j + 5], t);
+                h[j] = __builtin_elementwise_fma(gh2[3], VA[o][j + 6], t);
+            }
+            // q = floor(256 A) in the low 16 mantissa bits of A + 49152 (ulp 2^-8) ROUNDED DOWN: the eight additions run with the wave's f32
+            // rounding mode switched to -inf (everything else in this kernel is round-to-nearest-even).  Bits 8-15 are floor(A); a
+            // fraction byte of 0 or 255 puts A within 2^-8 = 3.9e-3 of an integer, four times the bound on |A - C|: undecided.
+            f2 r[BLUR_HALF];
+            static_assert(BLUR_HALF == 8, "the asm statement below adds eight pixel pairs");
+            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\ts_nop 1\n\t"
+                         "v_pk_add_f32 %0, %8, %16\n\tv_pk_add_f32 %1, %9, %16\n\tv_pk_add_f32 %2, %10, %16\n\tv_pk_add_f32 %3, %11, %16\n\t"
+                         "v_pk_add_f32 %4, %12, %16\n\tv_pk_add_f32 %5, %13, %16\n\tv_pk_add_f32 %6, %14, %16\n\tv_pk_add_f32 %7, %15, %16\n\t"
+                         "s_nop 1\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                         : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                         : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(h[4]), "v"(h[5]), "v"(h[6]), "v"(h[7]), "v"(magic));
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int j = jg + q;
-                    f2 h = gh2[3] * VA[o][j];
-                    h = __builtin_elementwise_fma(gh2[2], VA[o][j + 1], h);
-                    h = __builtin_elementwise_fma(gh2[1], VA[o][j + 2], h);
-                    h = __builtin_elementwise_fma(gh2[0], VA[o][j + 3], h);
-                    h = __builtin_elementwise_fma(gh2[1], VA[o][j + 4], h);
-                    h = __builtin_elementwise_fma(gh2[2], VA[o][j + 5], h);
-                    h = __builtin_elementwise_fma(gh2[3], VA[o][j + 6], h);
-                    // r1 = round(max(A - delta, 0) - 0.5), r2 = round(A + delta - 0.5): equal => floor(C) = r1 (see above); r2 - r1 is 0 or 1
-                    f2 z1 = h + zlo;
-                    const f2 z2 = h + zhi;
-                    z1.x = __builtin_fmaxf(z1.x, -0.5f);
-                    z1.y = __builtin_fmaxf(z1.y, -0.5f);
-                    const f2 r1 = z1 + magic, r2 = z2 + magic;
-                    lo4[q] = __float_as_uint(r1.x);
-                    hi4[q] = __float_as_uint(r1.y);
-                    amb = ((__float_as_uint(r2.x) - lo4[q]) << (16 * o + j)) | amb;
-                    amb = ((__float_as_uint(r2.y) - hi4[q]) << (16 * o + j + BLUR_HALF)) | amb;
-                }
-                // four low bytes -> one dword with three v_perm / v_or (the upper bytes of the rounded words hold the magic number)
-                ow[o][jg >> 2] = __builtin_amdgcn_perm(lo4[1], lo4[0], 0x0c0c0400u) | __builtin_amdgcn_perm(lo4[3], lo4[2], 0x04000c0cu);
-                ow[o][(jg + BLUR_HALF) >> 2] = __builtin_amdgcn_perm(hi4[1], hi4[0], 0x0c0c0400u) | __builtin_amdgcn_perm(hi4[3], hi4[2], 0x04000c0cu);
+            for (int wi = 0; wi < BLUR_STRIP / 4; wi++) {
+                // pixels 4 wi .. 4 wi + 3 of the strip: component wi >> 1 of the pairs 4 (wi & 1) .. 4 (wi & 1) + 3
+                unsigned q4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) q4[t] = __float_as_uint((wi >> 1) ? r[4 * (wi & 1) + t].y : r[4 * (wi & 1) + t].x);
+                const unsigned a01 = __builtin_amdgcn_perm(q4[1], q4[0], 0x04000501u), a23 = __builtin_amdgcn_perm(q4[3], q4[2], 0x04000501u);
+                ow[o][wi] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);               // floor(A) of the four pixels
+                const unsigned fr = __builtin_amdgcn_perm(a23, a01, 0x07060302u);       // floor(256 A) mod 256
+                // y = (f ^ f << 1) & 0xFE is zero exactly for fraction bytes 0 and 255; ~y & (y - 0x01010101) has bit 7 of every zero byte of
+                // y set (and possibly that of a byte of value 1 above one, which only lists a decided pixel as well)
+                const unsigned y = (fr ^ (fr << 1)) & 0xFEFEFEFEu;
+                const unsigned z = ~y & (y - 0x01010101u);
+                constexpr int k = 0;
+                (void)k;
+                amb |= (z >> (4 * o + wi)) & (0x80808080u >> (4 * o + wi));
             }
         }
         store_rows(ow);
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
         while (amb) {
             const int pos = __builtin_ctz(amb);
             amb &= amb - 1;
-            const int o = pos >> 4, p = pos & 15;
+            const int k = 7 - (pos & 7), o = k >> 2, p = 4 * (k & 3) + (pos >> 3);
             if (p < n_valid && y + o < H - JSORB_BORDER) {
                 const int idx = atomicAdd(&s_namb, 1);
                 if (idx < BLUR_AMB_CAP) s_amb[idx] = (unsigned short)((BLUR_ROWS * ty + o) * BLUR_TW + BLUR_STRIP * tx + p);

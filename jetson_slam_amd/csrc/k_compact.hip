@@ -15,7 +15,7 @@ __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned lon
                                                   int *__restrict__ row_tab, int *__restrict__ counts_host)
 {
     __shared__ int wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);
     const int b = blockIdx.x;
     const unsigned long long *tin = tile_out + (size_t)b * g.T;
     unsigned long long *kout = kp + (size_t)b * g.T;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     __shared__ int s_base[CMP_MAX_CHUNKS * 16];
     __shared__ int s_wtot[16];
     __shared__ int s_total;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);
     const int b = blockIdx.x, T = g.T;
     const unsigned long long *tin = tile_out + (size_t)b * T;
     unsigned long long *kout = kp + (size_t)b * T;

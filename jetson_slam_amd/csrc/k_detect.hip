@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
     // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
     // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
     asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));

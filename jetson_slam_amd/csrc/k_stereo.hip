@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
 // generic form (any number of keypoints): three passes over the distances in memory, bin searches by thread 0
 __device__ __forceinline__ int block256_exclusive_scan(int v, int *s_w, int &total)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);
     const int incl = wave_inclusive_scan_i32(v);
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
@@ -298,7 +298,7 @@ struct MedianShared {
 template <class ForEach>
 __device__ __forceinline__ float median_threshold(MedianShared &sm, int tid, ForEach for_each, int &nv_out)
 {
-    const int wave = tid >> 6;
+    const int wave = uniform_i32(tid >> 6);
     for_each([&](int d) { if (d >= 0) atomicAdd(&sm.hist[wave][d >> MED_BIN_SHIFT], 1); });
     __syncthreads();
     int nv;
