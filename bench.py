@@ -163,14 +163,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_init_s = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("JSORB_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for the test hook above
+        t_init = time.perf_counter()
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(8, dtype=torch.int32, device=dev)     # communicator set-up (rings over xGMI) happens at the first collective:
+            dist.all_reduce(warm)                                    # done here, outside every timed region, and reported
+            torch.cuda.synchronize(dev)
         else:
             dist.init_process_group(backend)
+        rccl_init_s = time.perf_counter() - t_init
     gloo = world > 1 and os.environ.get("JSORB_BENCH_BACKEND", "nccl") != "nccl"
 
     cfg = CONFIGS[args.config]
@@ -188,7 +194,12 @@ def main():
     # step is a different image pair (up to 128 unique per rank)
     n_unique = args.unique if args.unique > 0 else min(P, 128)
     n_unique = max(1, min(n_unique, P))
-    host_pairs = [synth_stereo_pair(args.seed_base + rank * 1000 + i, H, W) for i in range(n_unique)]
+    # ONE global list of P * world pairs per step, cut into contiguous blocks (jetson_slam_amd.batch.shard_range): pair p of the step is the
+    # synthetic pair with seed seed_base + p and belongs to the rank whose block holds p
+    from jetson_slam_amd.batch import shard_range
+    p_first, p_end = shard_range(P * world, rank, world)
+    assert p_end - p_first == P
+    host_pairs = [synth_stereo_pair(args.seed_base + p_first + i, H, W) for i in range(n_unique)]
     left_u = np.stack([p[0] for p in host_pairs])
     right_u = np.stack([p[1] for p in host_pairs])
     idx = np.arange(P) % n_unique
@@ -301,10 +312,20 @@ def main():
             n_bad += 1
     parity_local = n_bad == 0
     counts_ok = True
-    if world > 1:   # the gathered table of the last step must hold every rank's own counts
+    if world > 1:
+        # EVERY rank checks EVERY row of the table the last step's all_gather delivered to it: the expected table is the oracle's counts of
+        # all P * world pairs in global pair order (each rank's oracle computes its own block from the seeds; the blocks are exchanged with a
+        # second, untimed all_gather)
         torch.cuda.synchronize(dev)
-        mine = gathered[rank].cpu().numpy().reshape(-1, 3)
-        counts_ok = bool(np.array_equal(mine[:n_unique], o_counts[:n_unique]))
+        exp_local = torch.from_numpy(np.ascontiguousarray(o_counts[np.arange(P) % n_unique], dtype=np.int32)).reshape(-1)
+        if gloo:
+            exp_parts = [torch.zeros_like(exp_local) for _ in range(world)]
+            dist.all_gather(exp_parts, exp_local)
+        else:
+            exp_dev = exp_local.to(dev)
+            exp_parts = [torch.zeros_like(exp_dev) for _ in range(world)]
+            dist.all_gather(exp_parts, exp_dev)
+        counts_ok = all(bool(torch.equal(gathered[r_].cpu(), exp_parts[r_].cpu())) for r_ in range(world))
         flag = torch.tensor([1 if (parity_local and counts_ok) else 0], dtype=torch.int32, device="cpu" if gloo else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         parity = bool(flag.item())
@@ -366,6 +387,19 @@ def main():
             a[1] += n
         e.enable_kernel_timing(False)
 
+    # ---- north-star regime (i) at N > 1: every rank streams its own pairs from its own pinned host buffers at the same time (per-GPU PCIe
+    # links; no inter-GPU traffic); rank 0 reports the sum and the per-GPU rates ----
+    hs_multi = None
+    if world > 1 and not args.no_extras and args.config == "c2" and not strong and args.tile <= 0:
+        dist.barrier()
+        hs = measure_host_streamed(orb, torch, cfg, left_u, right_u, dev)
+        mine = torch.tensor([hs["value"], hs["pcie_gb_per_s"]], dtype=torch.float64, device="cpu" if gloo else dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        vals = [[float(x) for x in q.cpu()] for q in parts]
+        hs_multi = {"value": round(sum(v[0] for v in vals), 1), "unit": "stereo pairs/s", "per_gpu": [round(v[0], 1) for v in vals],
+                    "pcie_gb_per_s_per_gpu": [round(v[1], 2) for v in vals], "pcie_gb_per_s": round(sum(v[1] for v in vals), 2),
+                    "sample": "all %d ranks at the same time, each: %s" % (world, hs["sample"])}
     if rank == 0:
         ab, Ppx, T = algo_bytes_per_pair(exl)
         per_step_ms = {k: v[0] / max(1, args.profile_steps) for k, v in kt.items()}
@@ -392,9 +426,20 @@ def main():
                 "pipeline_achieved": round(ab * pairs_per_s / world / 1e9, 1),
                 "pipeline_frac": round(ab * pairs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step_ms.items()}}
+        props = torch.cuda.get_device_properties(dev)
+        vv = valu_view(args.config if args.tile <= 0 else "", pairs_per_s / world, props.multi_processor_count, 2.4e9)
+        if vv:
+            roof.update(vv)
+        if not args.no_extras:
+            pm = measure_copy_peak(torch, dev)
+            roof["peak_measured"] = pm
+            roof["peak_measured_what"] = "1 GiB device-to-device copy, read + write bytes, best of 6 (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)"
+            roof["frac_of_measured_peak"] = round(achieved / pm, 4)
+            roof["pipeline_frac_of_measured_peak"] = round(ab * pairs_per_s / world / 1e9 / pm, 4)
         cpu = None
-        host_streamed = None
+        host_streamed = hs_multi
         frame_latency = None
+        other = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, left_u[:16], right_u[:16])
         if world == 1 and not args.no_extras:
@@ -405,6 +450,15 @@ def main():
             for h in handles:
                 h.close()
             frame_latency = measure_frame_latency(cfg, left_u[0], right_u[0])
+            if args.config == "c2" and args.tile <= 0 and not strong:
+                # BASELINE C3 / C5 and the "nominal feature count" tiles of SURVEY 8(d), ~1 s each, every unique pair checked
+                other = {}
+                for key, (nm, tl, pp, nu) in {"c3": ("c3", 0, 64, 16), "c5": ("c5", 0, 64, 8), "c2_tile58": ("c2", 58, 128, 16),
+                                              "c3_tile46": ("c3", 46, 64, 16), "c5_tile52": ("c5", 52, 64, 8)}.items():
+                    try:
+                        other[key] = measure_other_config(orb, torch, dev, nm, tl, pp, nu)
+                    except Exception as e:      # never let a side measurement break the contract line
+                        other[key] = {"error": str(e)[:200]}
         n0 = int(o_counts[0][0])
         out = {
             "metric": "stereo pairs/s (FAST+ORB extract L+R + stereo match)", "value": round(pairs_per_s, 1), "unit": "stereo pairs/s",
@@ -421,12 +475,129 @@ def main():
                        "block_ms_min": round(min(blocks) * 1e3, 3), "block_ms_max": round(max(blocks) * 1e3, 3)},
             "parity_vs_oracle": parity, "parity_pairs_checked": n_unique * world, "gathered_counts_ok": counts_ok if world > 1 else None,
             "roofline": roof, "cpu_baseline": cpu, "host_streamed": host_streamed, "frame_latency_us": frame_latency, "c4_batch64": c4,
+            "other_configs": other, "rccl_init_s": None if rccl_init_s is None else round(rccl_init_s, 3),
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_copy_peak(torch, dev, gib=1.0, reps=6):
+    """"confirm on the box with a copy kernel and state the measured peak" - a 1 GiB device-to-device copy (16 B per lane on
+    both sides), read + write bytes over the best of `reps` event-timed runs."""
+    n = int(gib * (1 << 30)) // 16
+    src = torch.empty((n, 4), dtype=torch.int32, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    best = None
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src)
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    torch.cuda.empty_cache()
+    return round(2.0 * n * 16 / (best * 1e-3) / 1e9, 1)
+
+
+def valu_view(config, pairs_per_s, n_cus, clock_hz):
+    """What actually bounds the path: vector-ALU issue.  SQ_INSTS_VALU per kernel launch comes from the builder's rocprofv3 PMC pass
+    (profiles/valu_counters.json, condensed from profiles/r03_sq_counters.csv: 128 images per extract-side launch, 128 pairs per
+    stereo-side launch) - NOT measured in this run; a SIMD issues at most one VALU wave-instruction per 4 clocks."""
+    path = os.path.join(ROOT, "profiles", "valu_counters.json")
+    try:
+        tj = json.load(open(path))
+        k = tj[config]
+        per_pair = (2.0 * sum(v for n, v in k["extract_side"].items()) + sum(v for n, v in k["stereo_side"].items())) / float(tj["_pairs_per_launch"])
+        peak = n_cus * 4 * clock_hz / 4.0                     # VALU wave-instructions per second the chip can issue
+        return {"valu_wave_instr_per_pair": round(per_pair), "valu_wave_instr_per_128_pairs": round(per_pair * 128),
+                "valu_issue_frac": round(per_pair * pairs_per_s / peak, 4),
+                "valu_issue_peak": "%d CUs x 4 SIMDs x %.2f GHz / 4 clk" % (n_cus, clock_hz / 1e9),
+                "valu_source": tj.get("_source", "profiles/valu_counters.json") + " (builder-measured rocprofv3 PMC pass, NOT measured in this run)"}
+    except Exception:
+        return None
+
+
+def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seconds=0.8, cache={}):
+    """The other BASELINE configurations in the driver-run line: device-resident batches of P pairs through ONE handle pair, every unique pair
+    checked against the oracle, per-kernel hipEvent pass for the dominant kernel's roofline fraction."""
+    from jetson_slam_amd.synth import synth_stereo_pair
+    from oracle import pyoracle as po
+    H, W, L, tile, th, fx, bf = CONFIGS[name]
+    if tile_override:
+        tile = tile_override
+    if name not in cache:
+        prs = [synth_stereo_pair(1 + i, H, W) for i in range(n_unique)]
+        cache[name] = (np.stack([q[0] for q in prs]), np.stack([q[1] for q in prs]))
+    left_u, right_u = cache[name]
+    idx = np.arange(P) % left_u.shape[0]
+    left_d, right_d = torch.from_numpy(left_u[idx]).to(dev), torch.from_numpy(right_u[idx]).to(dev)
+    mk = lambda: orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, device_id=dev.index or 0, max_batch=P)
+    a, b = mk(), mk()
+    mb = bf / fx
+
+    def step():
+        a.extract_batch_device_async(left_d.data_ptr(), H * W, W, P, keep=left_d)
+        b.extract_batch_device_async(right_d.data_ptr(), H * W, W, P, keep=right_d)
+        orb.stereo_match_batch_async(a, b, mb, bf)
+
+    def fence():
+        a.sync(); b.sync()
+    for _ in range(3):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        step()
+    fence()
+    n = max(4, int(4 * seconds / max(time.perf_counter() - t0, 1e-6)))
+    blocks = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        blocks.append((time.perf_counter() - t0) / n)
+    dt = median(blocks)
+    okw = dict(height=H, width=W, n_levels=L, tile_h=tile, tile_w=tile, th_fast_max=th)
+    o_digest, o_counts = po.pairs_digest(left_u, right_u, mb, bf, usable_cores(), **okw)
+    bad = 0
+    for i in range(left_u.shape[0]):
+        u, d, st = orb.stereo_result(a, i)
+        got = po.digest_arrays([a.keypoints(i), a.descriptors(i), b.keypoints(i), b.descriptors(i), u, d])
+        if got != int(o_digest[i]) or [a.n_keypoints(i), b.n_keypoints(i), st["n_final"]] != o_counts[i].tolist():
+            bad += 1
+    one = torch.cuda.Stream(dev)
+    for e in (a, b):
+        e.set_stream(one.cuda_stream)
+        e.reset_kernel_timing()
+        e.enable_kernel_timing(True)
+    for _ in range(3):
+        step()
+    fence()
+    kt = {}
+    for e in (a, b):
+        for k, (ms, cnt) in e.kernel_times().items():
+            x = kt.setdefault(k, [0.0, 0])
+            x[0] += ms; x[1] += cnt
+    ab, Ppx, T = algo_bytes_per_pair(a)
+    per_step = {k: v[0] / 3.0 for k, v in kt.items() if v[1]}
+    dom = max(per_step, key=per_step.get)
+    avg_ms = kt[dom][0] / kt[dom][1]
+    units = P if dom in ("k_stereo", "k_median") else P / 2.0
+    pps = P / dt
+    out = {"workload": WORKLOAD_NAMES[name] + (" [tile overridden: %d]" % tile_override if tile_override else "") + " (cap %d kp/image)" % T,
+           "value": round(pps, 1), "unit": "stereo pairs/s", "ms_per_step": round(dt * 1e3, 4), "pairs_per_step": P,
+           "keypoints_image0": int(o_counts[0][0]), "parity_vs_oracle": bad == 0, "parity_pairs_checked": int(left_u.shape[0]),
+           "algo_bytes_per_pair": ab, "pipeline_frac": round(ab * pps / 1e9 / HBM_PEAK_GBS, 4),
+           "kernel": dom, "frac": round(ab * units / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4),
+           "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()}}
+    a.close(); b.close()
+    return out
 
 
 def measure_host_streamed(orb, torch, cfg, left_u, right_u, dev, P=256, seconds=1.5):
