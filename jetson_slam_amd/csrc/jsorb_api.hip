@@ -1090,8 +1090,16 @@ int jsorb_extract_batch_host_async(jsorb_extractor *e, const uint8_t *host_image
 static int extract_batch_device_enqueue(jsorb_extractor *e, const uint8_t *dev_images, size_t image_stride, int step, int n_images)
 {
     const LevelDesc &l0 = e->g.lv[0];
-    const bool in_place = (step % 16 == 0) && (((uintptr_t)dev_images) % 16 == 0) && (image_stride % 16 == 0);   // kernels stage with 16-byte loads
-    if (in_place) {   // level 0 is read where it lies: no copy of the grayscale plane
+    // Level 0 is read where it lies, whatever its alignment (round 3): the kernels' 16-byte staging loads of a plane whose rows are not
+    // 16-byte aligned (a dense 1241-pixel-wide KITTI plane) are unaligned vector-memory accesses - about twice the cost per cache line
+    // for those loads, in kernels that are instruction-issue bound - instead of a copy kernel over the whole plane first (7 % of the
+    // KITTI-shaped configuration's kernel time).  Every 16-byte chunk a kernel samples lies inside its row; chunks that cross the end of a
+    // row are zero-filled (k_detect, k_blur: never sampled), bounds-checked (k_pyramid) or continue into the next row of the same image
+    // (k_describe, k_stereo: rows at least 5 above the last).  JSORB_COPY_UNALIGNED=1 restores the copy.
+    static const bool copy_unaligned = getenv("JSORB_COPY_UNALIGNED") && atoi(getenv("JSORB_COPY_UNALIGNED")) != 0;
+    const bool aligned16 = (step % 16 == 0) && (((uintptr_t)dev_images) % 16 == 0) && (image_stride % 16 == 0);
+    const bool in_place = aligned16 || !copy_unaligned;
+    if (in_place) {   // no copy of the grayscale plane
         e->src.l0 = dev_images; e->src.l0_stride = image_stride; e->src.l0_pitch = step;
     } else {
         // rows that are not 16-byte aligned: one copy kernel per lane brings level 0 into the pitched slab (run_pipeline, lane stream)
