@@ -664,6 +664,10 @@ def measure_frame_latency(cfg, left, right, frames=300):
             out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=dict(env, JSORB_PERSISTENT_THREADS="1"),
                                  capture_output=True, text=True, timeout=120)
             res["total_us_median_persistent_threads"] = json.loads(out.stdout.strip().splitlines()[-1])["total_us_median"]
+            # the shipped Frame's shape: four SyncedMem members constructed and destroyed with every frame (Frame.h:234-237)
+            out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=dict(env, JSORB_FRESH_SYNCEDMEM="1"),
+                                 capture_output=True, text=True, timeout=120)
+            res["total_us_median_fresh_syncedmem_per_frame"] = json.loads(out.stdout.strip().splitlines()[-1])["total_us_median"]
             return res
         except Exception as e:      # never let a side measurement break the contract line
             return {"error": str(e)[:200]}

@@ -66,6 +66,10 @@ enum { JSORB_K_PYRAMID = 0, JSORB_K_DETECT, JSORB_K_COMPACT, JSORB_K_BLUR, JSORB
 /* ---- lifetime ---- */
 /* mask: NULL (no mask => all 255) or a height*width u8 level-0 mask in host memory. */
 int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extractor **out);
+/* The mask at ITS OWN size (mask_width x mask_height, any size): every level, level 0 included, is resized from it directly with
+ * cv::resize(INTER_NN)'s index rule - what orb_gpu.cpp:77-81 does with whatever image the yaml names.  jsorb_create is this call with
+ * the level-0 size. */
+int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mask_width, int mask_height, jsorb_extractor **out);
 void jsorb_destroy(jsorb_extractor *e);
 const char *jsorb_last_error(const jsorb_extractor *e);
 const char *jsorb_version(void);
@@ -132,7 +136,9 @@ int jsorb_copy_angles(const jsorb_extractor *e, int image, float *host_dst);
  * ORBmatcher::TH_HIGH/TH_LOW = 100/50 (ORBmatcher.cpp:24-25). */
 int jsorb_stereo_match(jsorb_extractor *left, jsorb_extractor *right, float mb, float mbf, int th_high, int th_low,
                        float *u_right, float *depth, jsorb_stereo_stats *stats);
-/* Speculative match (on by default, JSORB_SPECULATE=0 or the call below turn it off).  After one jsorb_stereo_match on a (left, right)
+/* Speculative match: OFF unless asked for - jsorb_set_speculative_stereo(left, 1), which include/jsorb_compat.hpp calls when it sees the
+ * Frame stereo call shape (ORB_compute_stereo_match / ComputeStereoMatches), or JSORB_SPECULATE=1; JSORB_SPECULATE=0 forbids it whatever
+ * the caller asks for.  A mono / RGB-D flow (one extractor, no match) never arms it.  After one jsorb_stereo_match on a (left, right)
  * pair of single-image handles, the library enqueues the same match, with the same mb / mbf / thresholds, right behind the NEXT pair of
  * single-image extracts on the GPU (the extract call that arrives second does it), so that the following jsorb_stereo_match on that
  * pair finds its result finished instead of paying a host round trip between extract and match.  The result is adopted only when the

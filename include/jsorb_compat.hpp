@@ -17,8 +17,10 @@
 #ifndef JSORB_COMPAT_HPP
 #define JSORB_COMPAT_HPP
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -39,32 +41,111 @@ typedef int cudaError_t;
 
 namespace orb_cuda {
 
+// Buffer pairs (pinned host + device) released by SyncedMem objects are parked here and handed to the next object that asks for the same
+// capacity.  The reference's Frame holds four SyncedMem members (Frame.h:234-237, the static variant is commented out), so EVERY frame
+// runs cudaMallocHost + cudaMalloc four times and frees them again; here a steady-state frame allocates nothing.  Per process, bounded,
+// guarded by a mutex (the two extractor threads of a stereo frame release / acquire concurrently).
+namespace detail {
+struct SyncedBufferCache {
+    struct Entry { size_t bytes; void *cpu, *gpu; };
+    std::mutex mu;
+    std::vector<Entry> free_list;
+    std::vector<cudaStream_t> free_streams;         // creating and destroying a HIP stream costs milliseconds: the private streams are recycled too
+    static SyncedBufferCache &get() { static SyncedBufferCache c; return c; }
+    int take_stream(cudaStream_t *st)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!free_streams.empty()) { *st = free_streams.back(); free_streams.pop_back(); return JSORB_OK; }
+        }
+        return jsorb_mem_stream_create(st);
+    }
+    void give_stream(cudaStream_t st)
+    {
+        if (!st) return;
+        jsorb_mem_stream_sync(st);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free_streams.size() < 64) { free_streams.push_back(st); return; }
+        }
+        jsorb_mem_stream_destroy(st);
+    }
+    bool take(size_t bytes, void **cpu, void **gpu)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < free_list.size(); i++)
+            if (free_list[i].bytes == bytes) {
+                *cpu = free_list[i].cpu; *gpu = free_list[i].gpu;
+                free_list[i] = free_list.back(); free_list.pop_back();
+                return true;
+            }
+        return false;
+    }
+    void give(size_t bytes, void *cpu, void *gpu)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cpu && gpu && free_list.size() < 32) { free_list.push_back(Entry{bytes, cpu, gpu}); return; }
+        }
+        if (cpu) jsorb_mem_free_host(cpu);
+        if (gpu) jsorb_mem_free_device(gpu);
+    }
+    ~SyncedBufferCache()
+    {
+        for (auto &e : free_list) { jsorb_mem_free_host(e.cpu); jsorb_mem_free_device(e.gpu); }
+        for (auto st : free_streams) jsorb_mem_stream_destroy(st);
+    }
+};
+}
+
 // orb_cuda::SyncedMem<T> (synced_mem_holder.hpp:10-65, synced_mem_holder.cpp:8-199): a pinned host buffer + a device buffer of
 // capacity_ elements and a private stream.  Same semantics: resize() grows only and never clears; the to_* calls copy count_
 // (or the given count) elements; the *_async forms run on cu_stream_ (or the given stream) and sync_stream() waits for cu_stream_.
 // Errors are recorded in cu_error_ and otherwise ignored, as in the reference (every method there is void).
+// COPIES: the reference declares no copy operations, so a copied SyncedMem there aliases the original's buffers and stream (and frees
+// them twice).  Frame is copied and assigned all the time (Tracking.cpp:292/336/364/366: mCurrentFrame = Frame(...); Frame(mCurrentFrame)),
+// so the copy operations exist here, with the reference's aliasing made safe: a copy SHARES the buffers and the stream with the
+// original (a reference count decides who frees); an object that has to grow while it shares leaves the old buffers to the others.
 template <typename Dtype>
 class SyncedMem {
+    struct Owner { void *cpu = nullptr, *gpu = nullptr; cudaStream_t stream = nullptr; size_t bytes = 0; bool pitched = false; std::atomic<int> refs{1}; };
+
 public:
-    SyncedMem() : count_(0), capacity_(0), cpu_data_(nullptr), gpu_data_(nullptr), pitch_(0), cu_stream_(nullptr), cu_error_(0)
+    SyncedMem() : count_(0), capacity_(0), cpu_data_(nullptr), gpu_data_(nullptr), pitch_(0), cu_stream_(nullptr), cu_error_(0), own_(new Owner)
     {
-        cu_error_ = jsorb_mem_stream_create(&cu_stream_);
+        cu_error_ = detail::SyncedBufferCache::get().take_stream(&cu_stream_);
+        own_->stream = cu_stream_;
     }
-    ~SyncedMem()
+    ~SyncedMem() { release(); }
+    SyncedMem(const SyncedMem &o)
+        : count_(o.count_), capacity_(o.capacity_), cpu_data_(o.cpu_data_), gpu_data_(o.gpu_data_), pitch_(o.pitch_), cu_stream_(o.cu_stream_),
+          cu_error_(o.cu_error_), host_fresh_(o.host_fresh_), own_(o.own_)
     {
-        if (cu_stream_) { jsorb_mem_stream_sync(cu_stream_); jsorb_mem_stream_destroy(cu_stream_); }
-        cu_stream_ = nullptr;
-        if (cpu_data_) jsorb_mem_free_host(cpu_data_);
-        if (gpu_data_) jsorb_mem_free_device(gpu_data_);
+        if (own_) own_->refs.fetch_add(1);
     }
-    // the reference's implicit copy would double-free; moves are what std::vector<SyncedMem<T>>::resize needs
-    SyncedMem(const SyncedMem &) = delete;
-    SyncedMem &operator=(const SyncedMem &) = delete;
+    SyncedMem &operator=(const SyncedMem &o)
+    {
+        if (this == &o) return *this;
+        if (o.own_) o.own_->refs.fetch_add(1);
+        release();
+        count_ = o.count_; capacity_ = o.capacity_; cpu_data_ = o.cpu_data_; gpu_data_ = o.gpu_data_; pitch_ = o.pitch_; cu_stream_ = o.cu_stream_;
+        cu_error_ = o.cu_error_; host_fresh_ = o.host_fresh_; own_ = o.own_;
+        return *this;
+    }
     SyncedMem(SyncedMem &&o) noexcept
         : count_(o.count_), capacity_(o.capacity_), cpu_data_(o.cpu_data_), gpu_data_(o.gpu_data_), pitch_(o.pitch_), cu_stream_(o.cu_stream_),
-          cu_error_(o.cu_error_), host_fresh_(o.host_fresh_)
+          cu_error_(o.cu_error_), host_fresh_(o.host_fresh_), own_(o.own_)
     {
-        o.count_ = o.capacity_ = 0; o.cpu_data_ = nullptr; o.gpu_data_ = nullptr; o.cu_stream_ = nullptr;
+        o.count_ = o.capacity_ = 0; o.cpu_data_ = nullptr; o.gpu_data_ = nullptr; o.cu_stream_ = nullptr; o.own_ = nullptr;
+    }
+    SyncedMem &operator=(SyncedMem &&o) noexcept
+    {
+        if (this == &o) return *this;
+        release();
+        count_ = o.count_; capacity_ = o.capacity_; cpu_data_ = o.cpu_data_; gpu_data_ = o.gpu_data_; pitch_ = o.pitch_; cu_stream_ = o.cu_stream_;
+        cu_error_ = o.cu_error_; host_fresh_ = o.host_fresh_; own_ = o.own_;
+        o.count_ = o.capacity_ = 0; o.cpu_data_ = nullptr; o.gpu_data_ = nullptr; o.cu_stream_ = nullptr; o.own_ = nullptr;
+        return *this;
     }
 
     void resize(int count)
@@ -73,34 +154,39 @@ public:
         host_fresh_ = false;
         if (capacity_ < count_) {
             capacity_ = count_;
-            if (cpu_data_) jsorb_mem_free_host(cpu_data_);
-            cpu_data_ = nullptr;
-            note(jsorb_mem_alloc_host((size_t)capacity_ * sizeof(Dtype), (void **)&cpu_data_));
-            if (gpu_data_) jsorb_mem_free_device(gpu_data_);
-            gpu_data_ = nullptr;
-            note(jsorb_mem_alloc_device((size_t)capacity_ * sizeof(Dtype), (void **)&gpu_data_));
+            fresh_owner();
+            const size_t bytes = (size_t)capacity_ * sizeof(Dtype);
+            void *c = nullptr, *g = nullptr;
+            if (!detail::SyncedBufferCache::get().take(bytes, &c, &g)) {
+                note(jsorb_mem_alloc_host(bytes, &c));
+                note(jsorb_mem_alloc_device(bytes, &g));
+            }
+            cpu_data_ = (Dtype *)c; gpu_data_ = (Dtype *)g;
+            own_->cpu = c; own_->gpu = g; own_->bytes = bytes; own_->pitched = false;
         }
     }
     void resize_pitched(size_t width, size_t height)
     {
         count_ = (int)(width * height);
         host_fresh_ = false;
-        if (cpu_data_) jsorb_mem_free_host(cpu_data_);
-        cpu_data_ = nullptr;
-        note(jsorb_mem_alloc_host((size_t)count_ * sizeof(Dtype), (void **)&cpu_data_));
-        if (gpu_data_) jsorb_mem_free_device(gpu_data_);
-        gpu_data_ = nullptr;
-        note(jsorb_mem_alloc_device_pitched(width * sizeof(Dtype), height, (void **)&gpu_data_, &pitch_));
+        fresh_owner();
+        void *c = nullptr, *g = nullptr;
+        note(jsorb_mem_alloc_host((size_t)count_ * sizeof(Dtype), &c));
+        note(jsorb_mem_alloc_device_pitched(width * sizeof(Dtype), height, &g, &pitch_));
+        cpu_data_ = (Dtype *)c; gpu_data_ = (Dtype *)g;
+        own_->cpu = c; own_->gpu = g; own_->bytes = 0; own_->pitched = true;
     }
 
-    Dtype *cpu_data() { return cpu_data_; }
-    Dtype *gpu_data() { host_fresh_ = false; return gpu_data_; }      // the caller may write through it: the host copy is no longer known to be current
+    // the caller may write through either pointer: the other side is no longer known to be current (to_cpu() then copies, as
+    // synced_mem_holder.cpp:88-91 always does)
+    Dtype *cpu_data() { host_fresh_ = false; return cpu_data_; }
+    Dtype *gpu_data() { host_fresh_ = false; return gpu_data_; }
 
     void to_cpu(void) { to_cpu(count_); }
     void to_gpu(void) { to_gpu(count_); }
     void to_cpu(int count)
     {
-        if (host_fresh_ && count <= count_) return;      // ORBExtractor::extract already delivered the host copy with the device copy
+        if (host_fresh_ && count <= count_) return;      // ORBExtractor::extract already delivered the host copy with the device copy and nobody has asked for a pointer since
         note(jsorb_mem_d2h(cpu_data_, gpu_data_, (size_t)count * sizeof(Dtype)));
     }
     void to_gpu(int count) { host_fresh_ = false; note(jsorb_mem_h2d(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype))); }
@@ -134,11 +220,45 @@ public:
     cudaStream_t cu_stream_;
     cudaError_t cu_error_;
 
-    // set by ORB_GPU::extract when it fills both sides in one go (the four blocking to_cpu() of Frame.cpp:119-122 then cost nothing)
+    // set by ORB_GPU::extract when it fills both sides in one go (the four blocking to_cpu() of Frame.cpp:119-122 then cost nothing);
+    // cleared by anything that hands out a pointer or moves data
     bool host_fresh_ = false;
 
 private:
+    Owner *own_;
     void note(int rc) { if (rc != JSORB_OK) cu_error_ = rc; }
+    static void destroy(Owner *o)
+    {
+        detail::SyncedBufferCache::get().give_stream(o->stream);      // (waits for the stream's work first)
+        if (o->pitched) { if (o->cpu) jsorb_mem_free_host(o->cpu); if (o->gpu) jsorb_mem_free_device(o->gpu); }
+        else if (o->cpu || o->gpu) detail::SyncedBufferCache::get().give(o->bytes, o->cpu, o->gpu);
+        delete o;
+    }
+    void release()
+    {
+        if (own_ && own_->refs.fetch_sub(1) == 1) destroy(own_);
+        own_ = nullptr; cpu_data_ = nullptr; gpu_data_ = nullptr; cu_stream_ = nullptr;
+    }
+    // before new buffers are attached: sole owner -> the old ones go back to the cache; shared -> they stay with the other objects and
+    // this one continues with an owner (and stream) of its own
+    void fresh_owner()
+    {
+        if (own_ && own_->refs.load() == 1) {
+            if (own_->pitched) { if (own_->cpu) jsorb_mem_free_host(own_->cpu); if (own_->gpu) jsorb_mem_free_device(own_->gpu); }
+            else if (own_->cpu || own_->gpu) {
+                if (own_->stream) jsorb_mem_stream_sync(own_->stream);
+                detail::SyncedBufferCache::get().give(own_->bytes, own_->cpu, own_->gpu);
+            }
+            own_->cpu = own_->gpu = nullptr;
+        } else {
+            if (own_) own_->refs.fetch_sub(1);
+            own_ = new Owner;
+            cu_stream_ = nullptr;
+            note(detail::SyncedBufferCache::get().take_stream(&cu_stream_));
+            own_->stream = cu_stream_;
+        }
+        cpu_data_ = nullptr; gpu_data_ = nullptr;
+    }
 };
 
 // orb_cuda::ORB_Search_by_projection_project_on_frame (orb_matcher.hpp:12-18, orb_matcher.cu:62-89): synchronous, device pointers
@@ -176,6 +296,7 @@ public:
             const unsigned char *mask_plane = nullptr, int max_batch = 1)
     {
         std::vector<unsigned char> mask;
+        int mask_w = im_width, mask_h = im_height;
         if (!mask_plane && !str_mask.empty()) {
             // orb_gpu.cpp:64-75: cv::imread(str_mask); an unreadable file means "no mask" there (mask.empty() -> all 255)
             int mw = 0, mh = 0;
@@ -199,27 +320,16 @@ public:
             if (rc == JSORB_OK) have = true;
             else if (rc != JSORB_ERR_STATE) throw std::invalid_argument(std::string("jsorb: mask file: ") + jsorb_mask_image_last_error());
 #endif
-            if (have) {
-                // the reference resizes whatever size the mask has to every level (level 0 included) with INTER_NN; the ABI takes the
-                // level-0 plane, so a mask of another size is first brought to level-0 size with the same index rule
-                if (mw != im_width || mh != im_height) {
-                    std::vector<unsigned char> r((size_t)im_width * im_height);
-                    const double ifx = 1.0 / ((double)im_width / mw), ify = 1.0 / ((double)im_height / mh);
-                    for (int y = 0; y < im_height; y++) {
-                        int sy = (int)(y * ify); if (sy > mh - 1) sy = mh - 1;
-                        for (int x = 0; x < im_width; x++) { int sx = (int)(x * ifx); if (sx > mw - 1) sx = mw - 1; r[(size_t)y * im_width + x] = mask[(size_t)sy * mw + sx]; }
-                    }
-                    mask.swap(r);
-                }
-                mask_plane = mask.data();
-            }
+            // the reference resizes whatever size the mask has to EVERY level (level 0 included) with INTER_NN (orb_gpu.cpp:77-81): the mask goes
+            // through the ABI at its own size and the library resizes each level from it directly
+            if (have) { mask_plane = mask.data(); mask_w = mw; mask_h = mh; }
         }
         jsorb_params p{};
         p.height = im_height; p.width = im_width; p.n_levels = n_levels; p.scale_factor = scale_factor;
         p.fast_n_min = FAST_N_MIN; p.fast_n_max = FAST_N_MAX; p.th_fast_min = th_FAST_MIN; p.th_fast_max = th_FAST_MAX;
         p.tile_h = tile_h; p.tile_w = tile_w; p.fixed_multi_scale_tile_size = fixed_multi_scale_tile_size;
         p.apply_nms_ms = apply_nms_ms; p.nms_ms_mode_gpu = nms_ms_mode_gpu; p.device_id = device_id; p.max_batch = max_batch;
-        const int rc = jsorb_create(&p, mask_plane, &handle_);
+        const int rc = jsorb_create_masked(&p, mask_plane, mask_w, mask_h, &handle_);
         if (rc != JSORB_OK) {
             std::string msg = handle_ ? jsorb_last_error(handle_) : "jsorb_create failed";
             if (handle_) jsorb_destroy(handle_);
@@ -278,6 +388,10 @@ public:
     {
         if (images_left.owner != this || !images_right.owner) throw std::invalid_argument("ORB_compute_stereo_match: pyramids do not belong to these extractors");
         jsorb_extractor *l = handle_, *r = images_right.owner->handle_;
+        // Frame's stereo call shape (two extracts, then this call, every frame): ask the library to run the NEXT frame's match right behind
+        // its two extracts on the GPU (jsorb.h, jsorb_set_speculative_stereo).  Opt-in here, not a library default: a mono / RGB-D
+        // flow never reaches this function.
+        if (!speculation_requested_) { jsorb_set_speculative_stereo(l, 1); speculation_requested_ = true; }
         const int n = jsorb_n_keypoints(l, 0);
         if (n < 0 || (size_t)n != mvKeys.size() || (size_t)jsorb_n_keypoints(r, 0) != mvKeysRight.size())
             throw std::runtime_error("ORB_compute_stereo_match: keypoint vectors do not match the last extract of the handles");
@@ -296,6 +410,7 @@ public:
     std::vector<float> scale_, inv_scale_;
     ImagePyramid image_;
     jsorb_stereo_stats last_stereo_stats_{};
+    bool speculation_requested_ = false;
 
 private:
     jsorb_extractor *handle_ = nullptr;
@@ -395,6 +510,7 @@ inline void ComputeStereoMatches(ORBExtractor &left, ORBExtractor &right, float 
 {
     const int n = jsorb_n_keypoints(left.handle(), 0);
     if (n < 0) throw std::runtime_error("ComputeStereoMatches before extract");
+    if (!left.orb_gpu_->speculation_requested_) { jsorb_set_speculative_stereo(left.handle(), 1); left.orb_gpu_->speculation_requested_ = true; }
     mvuRight.assign(n, -1.0f);
     mvDepth.assign(n, -1.0f);
     float dummy = -1.0f;

@@ -39,7 +39,12 @@ struct TimedLaunch { int id; hipEvent_t a, b; };
 // stream of a few handle pairs its own (8 were not enough for bench.py, which keeps two sets of handles alive).  The variable is read when the HIP runtime initialises (its first API call), so this
 // constructor - run when the library is loaded - is early enough for a process that links the library or imports the Python binding
 // before it touches the GPU; an explicit setting by the user wins.  ("Runtime environment")
-__attribute__((constructor)) void jsorb_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// JSORB_NO_ENV=1 forbids it: an integrator who does not want a library to touch the process environment sets the variable itself (or not).
+__attribute__((constructor)) void jsorb_runtime_defaults()
+{
+    const char *no = getenv("JSORB_NO_ENV");
+    if (!(no && atoi(no) != 0)) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
 
 } // namespace
 
@@ -139,11 +144,17 @@ struct jsorb_extractor {
     // the 5-kernel chain of a single image as a HIP graph (captured on first use, replayed while the arguments stay the same): one
     // hipGraphLaunch instead of five kernel launches on the host's critical path (JSORB_FRAME_GRAPH=0 disables)
     hipGraphExec_t frame_graph = nullptr;
-    const void *fg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // l0 source, its pitch, main stream, the two caller-owned destinations, upload node
+    hipGraph_t frame_graph_tmpl = nullptr;          // the captured graph the executable one was instantiated from (owns the node handles)
+    hipGraphNode_t fg_describe_node = nullptr;      // its k_describe node: carries the caller-owned destinations of jsorb_extract_into
+    int32_t *fg_dst_kp = nullptr;                   // ... as currently set in the executable graph
+    uint8_t *fg_dst_desc = nullptr;
+    const void *fg_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // l0 source, its pitch, main stream, (unused x 2), upload node
     // single frame from pageable host memory: the calling thread copies the image into this pinned buffer and the first kernel of the
     // frame pulls it over PCIe (JSORB_KERNEL_UPLOAD=0: hipMemcpyAsync instead).  hipMemcpyAsync from pageable memory goes through a
     // staging buffer of the runtime that the two extractor threads of a stereo frame take turns on: the right image started ~20 us late.
     uint8_t *h_upload = nullptr;
+    hipEvent_t ev_upload_read = nullptr;   // recorded right behind k_upload_level0: the pinned buffer may be rewritten once it has fired
+    bool upload_inflight = false;
     int kernel_upload = 1;
     bool upload_pending = false;       // transient: run_pipeline starts the single-image chain with the upload kernel
     int fg_recaptures = 0;             // consecutive frames whose arguments differed from the captured ones
@@ -154,7 +165,8 @@ struct jsorb_extractor {
     jsorb_spec_state *spec = nullptr;
     unsigned long long spec_seq = 0;   // extract calls of this handle (written under spec->mu once paired)
     bool spec_single = false;          // the last extract was a single image on an untimed handle
-    int speculate = 1;                 // JSORB_SPECULATE=0 / jsorb_set_speculative_stereo(l, 0) disable
+    int speculate = 0;                 // opt-in: jsorb_set_speculative_stereo(l, 1) (the C++ shim does it when it sees Frame's call shape) or JSORB_SPECULATE=1
+    int speculate_env = -1;            // JSORB_SPECULATE, when set, wins over the call (0: never, 1: always)
     float *sp_u = nullptr, *sp_d = nullptr, *h_sp_u = nullptr, *h_sp_d = nullptr;   // twin output buffers (left handle), swapped in on adoption
     const int *l1_view = nullptr;      // L1 distances of the last match: st_l1, or sp_l1 after an adopted speculative match (jsorb_copy_stereo_l1)
     int *sp_stats = nullptr, *h_sp_stats = nullptr, *sp_l1 = nullptr;   // sp_l1 / sp_aux: scratch of the speculative match (one pair)
@@ -500,6 +512,49 @@ int order_lanes_for_new_batch(jsorb_extractor *e, int K, int n, const hipStream_
     return JSORB_OK;
 }
 
+// ---- the single-frame graph (struct jsorb_extractor: frame_graph*) ----
+void frame_graph_drop(jsorb_extractor *e)
+{
+    if (e->frame_graph) { (void)hipGraphExecDestroy(e->frame_graph); e->frame_graph = nullptr; }
+    if (e->frame_graph_tmpl) { (void)hipGraphDestroy(e->frame_graph_tmpl); e->frame_graph_tmpl = nullptr; }
+    e->fg_describe_node = nullptr;
+    memset(e->fg_key, 0, sizeof e->fg_key);
+}
+
+hipGraphNode_t frame_graph_find_describe(hipGraph_t graph)
+{
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess || n == 0 || n > 64) return nullptr;
+    hipGraphNode_t nodes[64];
+    if (hipGraphGetNodes(graph, nodes, &n) != hipSuccess) return nullptr;
+    for (size_t i = 0; i < n; i++) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess || t != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams p{};
+        if (hipGraphKernelNodeGetParams(nodes[i], &p) == hipSuccess && p.func == describe_kernel_address()) return nodes[i];
+    }
+    return nullptr;
+}
+
+// The captured k_describe node writes the frame's keypoints / descriptors also into caller-owned device buffers (struct Deliver).  When
+// the caller's buffers differ from the ones in the executable graph - every frame with the reference's Frame, whose SyncedMem members
+// are per-Frame objects - the node's parameters are updated in place (a few microseconds on the host) instead of re-capturing the graph
+// (which the first version did, giving up on graphs after 8 frames).  false: not possible, capture again.
+bool frame_graph_set_destinations(jsorb_extractor *e)
+{
+    if (e->deliver_kp_dev == e->fg_dst_kp && e->deliver_desc_dev == e->fg_dst_desc) return true;
+    if (!e->fg_describe_node || !e->frame_graph) return false;
+    hipKernelNodeParams p{};
+    if (hipGraphKernelNodeGetParams(e->fg_describe_node, &p) != hipSuccess || !p.kernelParams) { (void)hipGetLastError(); return false; }
+    Deliver *dl = static_cast<Deliver *>(p.kernelParams[describe_kernel_deliver_arg()]);
+    if (!dl) return false;
+    dl->kp_dev = e->deliver_kp_dev;
+    dl->desc_dev = e->deliver_desc_dev;
+    if (hipGraphExecKernelNodeSetParams(e->frame_graph, e->fg_describe_node, &p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    e->fg_dst_kp = e->deliver_kp_dev; e->fg_dst_desc = e->deliver_desc_dev;
+    return true;
+}
+
 int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = nullptr)
 {
     const Geometry &g = e->g;
@@ -539,19 +594,31 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         }
         // single image on an untimed handle: replay the captured graph of the five launches when nothing they depend on has changed
         bool capturing = false;
-        if (direct && e->use_frame_graph && !e->timing && !e->nms_ms) {
-            const void *key[6] = {e->src.l0, (const void *)(uintptr_t)e->src.l0_pitch, st, e->deliver_kp_dev, e->deliver_desc_dev, e->upload_pending ? e->h_upload : nullptr};
+        // (only on the handle's own stream: a caller-provided stream may be the legacy / null stream, which cannot be captured, and a capture
+        // that fails half way would leave the CALLER's stream in capture mode)
+        if (direct && e->use_frame_graph && !e->timing && !e->nms_ms && st == e->own_stream) {
+            // The caller-owned destinations (jsorb_extract_into) are NOT part of the key: the reference's Frame builds fresh SyncedMem members
+            // every frame, so they change from frame to frame - the k_describe node of the instantiated graph gets them patched in
+            // (frame_graph_set_destinations) instead of the graph being captured again.
+            const void *key[6] = {e->src.l0, (const void *)(uintptr_t)e->src.l0_pitch, st, nullptr, nullptr, e->upload_pending ? e->h_upload : nullptr};
             if (e->frame_graph && memcmp(key, e->fg_key, sizeof key) == 0) {
                 e->fg_recaptures = 0;
-                HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
-                HIPCHK(e, hipEventRecord(e->lane_done[j], st));
-                continue;
+                if (!frame_graph_set_destinations(e)) { /* fall through to a fresh capture */ }
+                else {
+                    HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
+                    HIPCHK(e, hipEventRecord(e->lane_done[j], st));
+                    if (e->upload_pending) { HIPCHK(e, hipEventRecord(e->ev_upload_read, st)); e->upload_inflight = true; }
+                    continue;
+                }
             }
-            if (e->frame_graph) { (void)hipGraphExecDestroy(e->frame_graph); e->frame_graph = nullptr; }
-            if (++e->fg_recaptures > 8) e->use_frame_graph = 0;      // a caller that rotates its buffers: plain launches are cheaper than re-capturing
-            memcpy(e->fg_key, key, sizeof key);
-            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            capturing = true;
+            frame_graph_drop(e);
+            if (++e->fg_recaptures > 8) e->use_frame_graph = 0;      // a caller that rotates its INPUT buffers: plain launches are cheaper than re-capturing
+            if (e->use_frame_graph) {
+                memcpy(e->fg_key, key, sizeof key);
+                e->fg_dst_kp = e->deliver_kp_dev; e->fg_dst_desc = e->deliver_desc_dev;
+                HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                capturing = true;
+            }
         }
         // Software pipeline across the lanes: stage s of lane j starts when stage s of lane j-1 has finished, so that at any time
         // DIFFERENT stages are resident on the GPU (k_detect's sparse ring-test phases next to k_blur's FMA chains next to
@@ -577,15 +644,29 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
                                                              : Deliver{nullptr, nullptr, nullptr, nullptr, nullptr}));
 #undef JSORB_STAGE
         if (capturing) {
+            // Whatever happened between Begin and End (a launch error included), the stream must leave capture mode; on any failure the
+            // partial graph is dropped, the key forgotten, graphs switched off for this handle and the frame re-issued as plain launches.
             hipGraph_t graph = nullptr;
-            HIPCHK(e, hipStreamEndCapture(st, &graph));
-            const hipError_t gi = hipGraphInstantiate(&e->frame_graph, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (gi != hipSuccess) { e->frame_graph = nullptr; e->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(gi); return JSORB_ERR_HIP; }
-            HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
+            const hipError_t launch_err = hipGetLastError();
+            const hipError_t ec = hipStreamEndCapture(st, &graph);
+            hipError_t gi = ec != hipSuccess ? ec : launch_err;
+            if (gi == hipSuccess) gi = hipGraphInstantiate(&e->frame_graph, graph, nullptr, nullptr, 0);
+            if (gi == hipSuccess) {
+                e->frame_graph_tmpl = graph;                 // kept: its k_describe node is the handle for later parameter updates
+                e->fg_describe_node = frame_graph_find_describe(graph);
+                gi = hipGraphLaunch(e->frame_graph, st);
+            } else if (graph) (void)hipGraphDestroy(graph);
+            if (gi != hipSuccess) {
+                (void)hipGetLastError();
+                frame_graph_drop(e);
+                e->use_frame_graph = 0;
+                j--;                                         // redo this lane without a graph
+                continue;
+            }
         }
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
+        if (e->upload_pending) { HIPCHK(e, hipEventRecord(e->ev_upload_read, st)); e->upload_inflight = true; }      // (recorded behind the frame: an event record inside the captured graph is not an option on this runtime)
     }
     e->copy_kind = 0;
     e->upload_pending = false;
@@ -729,7 +810,13 @@ const char *jsorb_last_error(const jsorb_extractor *e) { return e ? e->err.c_str
 
 int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extractor **out)
 {
+    return jsorb_create_masked(params, mask, params ? params->width : 0, params ? params->height : 0, out);
+}
+
+int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mask_width, int mask_height, jsorb_extractor **out)
+{
     if (!params || !out) return JSORB_ERR_INVALID;
+    if (mask && (mask_width < 1 || mask_height < 1)) return JSORB_ERR_INVALID;
     *out = nullptr;
     jsorb_extractor *e = new (std::nothrow) jsorb_extractor();
     if (!e) return JSORB_ERR_INVALID;
@@ -754,7 +841,7 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));      // tuning hooks
     if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
     if (const char *sw = getenv("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
-    if (const char *sp = getenv("JSORB_SPECULATE")) e->speculate = atoi(sp);
+    if (const char *sp = getenv("JSORB_SPECULATE")) { e->speculate_env = atoi(sp) != 0; e->speculate = e->speculate_env; }
     if (const char *ku = getenv("JSORB_KERNEL_UPLOAD")) e->kernel_upload = atoi(ku);
     if (const char *hl = getenv("JSORB_HOST_LANES")) e->host_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(hl)));
     if (const char *tr = getenv("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
@@ -857,16 +944,18 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
     if (mask) {
         // orb_gpu.cpp:77-81: cv::resize(..., CV_INTER_NN) per level, then threshold (>10 -> 255).  The source index is OpenCV's
         // resizeNN one: ifx = 1./(dst/(double)src), sx = min(cvFloor(x*ifx), src-1) - NOT floor(x*src/dst), which differs on
-        // exact-integer quotients (752->626 column 313, 480->231 rows 77 and 154, ...).
+        // exact-integer quotients (752->626 column 313, 480->231 rows 77 and 154, ...).  The source is the mask AT ITS OWN SIZE, every level
+        // (level 0 included) resized from it directly as the reference does - resizing to level-0 size first and from there to the levels
+        // composes two floor() maps and can pick other source pixels.
         std::vector<uint8_t> m(g.slab_bytes, 0);
         for (int i = 0; i < g.L; i++) {
             const LevelDesc &lv = g.lv[i];
-            const double ifx = 1.0 / ((double)lv.W / (double)g.lv[0].W), ify = 1.0 / ((double)lv.H / (double)g.lv[0].H);
+            const double ifx = 1.0 / ((double)lv.W / (double)mask_width), ify = 1.0 / ((double)lv.H / (double)mask_height);
             for (int y = 0; y < lv.H; y++) {
-                const int sy = std::min((int)std::floor((double)y * ify), g.lv[0].H - 1);
+                const int sy = std::min((int)std::floor((double)y * ify), mask_height - 1);
                 for (int x = 0; x < lv.W; x++) {
-                    const int sx = std::min((int)std::floor((double)x * ifx), g.lv[0].W - 1);
-                    m[lv.img_off + (size_t)y * lv.pitch + x] = mask[(size_t)sy * g.lv[0].W + sx] > 10 ? 255 : 0;
+                    const int sx = std::min((int)std::floor((double)x * ifx), mask_width - 1);
+                    m[lv.img_off + (size_t)y * lv.pitch + x] = mask[(size_t)sy * mask_width + sx] > 10 ? 255 : 0;
                 }
             }
         }
@@ -891,7 +980,8 @@ void jsorb_destroy(jsorb_extractor *e)
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     if (e->has_readers)       // a stereo match enqueued through another handle may still be reading this handle's buffers
         for (int j = 0; j < e->readers_K; j++) (void)hipEventSynchronize(e->lane_readers_done[j]);
-    if (e->frame_graph) (void)hipGraphExecDestroy(e->frame_graph);
+    frame_graph_drop(e);
+    if (e->ev_upload_read) (void)hipEventDestroy(e->ev_upload_read);
     for (int j = 0; j < e->K; j++)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1015,10 +1105,14 @@ static int extract_batch_host_enqueue(jsorb_extractor *e, const uint8_t *host_im
         if ((rc = join_previous_on_main(e))) return rc;
         const double t0 = e->trace_host ? now_us() : 0.0;
         if (e->kernel_upload) {
-            if (!e->h_upload) HIPCHK(e, hipHostMalloc(&e->h_upload, img_bytes));
-            // the previous frame's upload kernel has read the pinned buffer when that frame's kernels are done (asynchronous callers
-            // that have not waited for it yet wait here)
-            if (e->mirror_pending && (rc = wait_event(e, e->lane_done[0], e->spin_wait != 0))) return rc;
+            if (!e->h_upload) {
+                HIPCHK(e, hipHostMalloc(&e->h_upload, img_bytes));
+                HIPCHK(e, hipEventCreateWithFlags(&e->ev_upload_read, hipEventDisableTiming));
+            }
+            // the previous frame's upload kernel must have read the pinned buffer before it is rewritten: its own event (asynchronous
+            // callers that have not waited for that frame yet wait here; a batch enqueued in between does not change what has to be waited for)
+            if (e->upload_inflight && (rc = wait_event(e, e->ev_upload_read, e->spin_wait != 0))) return rc;
+            e->upload_inflight = false;
             memcpy(e->h_upload, host_images, img_bytes);
             e->upload_pending = true;
         } else {
@@ -1504,8 +1598,8 @@ int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float m
 int jsorb_set_speculative_stereo(jsorb_extractor *l, int on)
 {
     if (!l) return JSORB_ERR_INVALID;
-    l->speculate = on ? 1 : 0;
-    if (!on && l->spec) { (void)hipSetDevice(l->device); spec_detach(l->spec); }
+    l->speculate = l->speculate_env >= 0 ? l->speculate_env : (on ? 1 : 0);
+    if (!l->speculate && l->spec) { (void)hipSetDevice(l->device); spec_detach(l->spec); }
     return JSORB_OK;
 }
 

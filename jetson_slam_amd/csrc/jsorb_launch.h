@@ -37,6 +37,8 @@ void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, ui
 void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *blur_slab,
                      const unsigned long long *kp, const int *counts, float *angles, uint8_t *desc, int32_t *out_kp,
                      int n_images, hipStream_t s, Deliver dl = Deliver{nullptr, nullptr, nullptr, nullptr, nullptr});
+const void *describe_kernel_address();    // host-side address of k_describe (identifies its node in a captured graph)
+int describe_kernel_deliver_arg();         // index of its `Deliver dl` argument
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,

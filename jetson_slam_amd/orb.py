@@ -37,7 +37,7 @@ EXPORTS = [
     "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
     "jsorb_mem_free_device", "jsorb_mem_stream_create", "jsorb_mem_stream_destroy", "jsorb_mem_stream_sync", "jsorb_mem_h2d", "jsorb_mem_d2h",
     "jsorb_mem_d2d", "jsorb_mem_h2d_async", "jsorb_mem_d2h_async", "jsorb_mem_d2d_async", "jsorb_mem_set_zero", "jsorb_mem_set_zero_async",
-    "jsorb_mem_last_error", "jsorb_read_mask_image", "jsorb_mask_image_last_error",
+    "jsorb_mem_last_error", "jsorb_read_mask_image", "jsorb_mask_image_last_error", "jsorb_create_masked",
 ]
 
 
@@ -76,6 +76,7 @@ def load_library(path=None):
     P, I, F = C.c_void_p, C.c_int, C.c_float
     sig = {
         "jsorb_create": (I, [C.POINTER(JsorbParams), P, C.POINTER(P)]),
+        "jsorb_create_masked": (I, [C.POINTER(JsorbParams), P, I, I, C.POINTER(P)]),
         "jsorb_destroy": (None, [P]),
         "jsorb_last_error": (C.c_char_p, [P]),
         "jsorb_version": (C.c_char_p, []),
@@ -165,19 +166,19 @@ class ORBExtractor:
         self._h = C.c_void_p()
         mask = None
         if isinstance(str_mask, str) and str_mask:
-            mask = read_mask_image(str_mask)                  # the reference's image path (None = unreadable = no mask, orb_gpu.cpp:69-73)
-            if mask is not None and mask.shape != (im_height, im_width):
-                # the reference resizes whatever size the mask has to every level with INTER_NN: bring it to level-0 size with the same index rule
-                sy = np.minimum(np.floor(np.arange(im_height) * (1.0 / (im_height / float(mask.shape[0])))).astype(np.int64), mask.shape[0] - 1)
-                sx = np.minimum(np.floor(np.arange(im_width) * (1.0 / (im_width / float(mask.shape[1])))).astype(np.int64), mask.shape[1] - 1)
-                mask = np.ascontiguousarray(mask[sy][:, sx])
+            # the reference's image path (None = unreadable = no mask, orb_gpu.cpp:69-73); whatever size the image has, every level is
+            # resized from it directly with INTER_NN (orb_gpu.cpp:77-81): it goes through the ABI at its own size
+            mask = read_mask_image(str_mask)
         elif str_mask is not None and not isinstance(str_mask, str):
-            mask = np.ascontiguousarray(str_mask, np.uint8)   # an (H, W) array instead of the reference's image path
-            assert mask.shape == (im_height, im_width)
+            mask = np.ascontiguousarray(str_mask, np.uint8)   # a 2-D array (any size) instead of the reference's image path
+            assert mask.ndim == 2
         self.params = JsorbParams(im_height, im_width, n_levels, scale_factor, FAST_N_MIN, FAST_N_MAX, th_FAST_MIN,
                                   th_FAST_MAX, tile_h, tile_w, int(fixed_multi_scale_tile_size), int(apply_nms_ms),
                                   int(nms_ms_mode_gpu), device_id, max_batch)
-        rc = self._lib.jsorb_create(C.byref(self.params), None if mask is None else mask.ctypes.data, C.byref(self._h))
+        if mask is None:
+            rc = self._lib.jsorb_create(C.byref(self.params), None, C.byref(self._h))
+        else:
+            rc = self._lib.jsorb_create_masked(C.byref(self.params), mask.ctypes.data, int(mask.shape[1]), int(mask.shape[0]), C.byref(self._h))
         if rc != 0:
             msg = self._lib.jsorb_last_error(self._h).decode() if self._h else "jsorb_create failed"
             if self._h:

@@ -12,6 +12,15 @@ struct ORBmatcher { static const int TH_HIGH = 100, TH_LOW = 50; };
 
 class Frame {
 public:
+    Frame() {}
+    // Frame.cpp:56-78: the reference's user-declared copy constructor (it does not copy the SyncedMem members).  Because it exists, the
+    // copy ASSIGNMENT Tracking uses (Tracking.cpp:292/336/364/366: mCurrentFrame = Frame(...)) is the implicit member-wise one - which
+    // needs SyncedMem to be copy-assignable.
+    Frame(const Frame &frame)
+        : mpORBextractorLeft(frame.mpORBextractorLeft), mpORBextractorRight(frame.mpORBextractorRight), mvKeys(frame.mvKeys), mvKeysRight(frame.mvKeysRight),
+          mvuRight(frame.mvuRight), mvDepth(frame.mvDepth), mDescriptors(frame.mDescriptors), mbf(frame.mbf), fx(frame.fx), mb(frame.mb), use_gpu_(frame.use_gpu_)
+    {
+    }
     Frame(const cv::Mat &imLeft, const cv::Mat &imRight, ORBExtractor *extractorLeft, ORBExtractor *extractorRight, float bf_, float fx_)
         : mpORBextractorLeft(extractorLeft), mpORBextractorRight(extractorRight), mbf(bf_), fx(fx_), use_gpu_(true)
     {
@@ -65,6 +74,16 @@ public:
 inline ORBExtractor *make_extractor(int h, int w, const std::string &str_mask)
 {
     return new ORBExtractor(h, w, 1.2f, 8, 9, 14, 7, 20, str_mask, 30, 30, false, true, true, true);
+}
+
+// Tracking::GrabImageStereo (Tracking.cpp:255-300) and Tracking::Track: a Frame is built, assigned and copied every frame
+inline void tracking_like(const cv::Mat &l, const cv::Mat &r, ORBExtractor *exl, ORBExtractor *exr)
+{
+    Frame mCurrentFrame, mLastFrame;
+    mCurrentFrame = Frame(l, r, exl, exr, 47.9f, 435.2f);      // Tracking.cpp:292
+    mLastFrame = Frame(mCurrentFrame);                          // Tracking.cpp:1000 (copy construction, then assignment)
+    Frame third(mLastFrame);
+    (void)third;
 }
 
 } // namespace Jetson_SLAM

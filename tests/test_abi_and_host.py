@@ -106,6 +106,17 @@ def test_cpp_compat_shim_compiles_and_links(libpath, tmp_path):
     assert os.path.exists(exe)
 
 
+def test_cpp_mono_frame_example_compiles_and_links(libpath, tmp_path):
+    """examples/mono_frame.cpp: the mono / RGB-D Frame constructor (Frame.cpp:253-330) with Tracking's assign-and-copy frame loop - needs
+    SyncedMem's copy operations (run on the GPU box by tests/test_gpu_parity.py::test_cpp_mono_frame_example_and_frame_copies)"""
+    import subprocess
+    exe = str(tmp_path / "mono_frame")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "mono_frame.cpp"), "-L", os.path.dirname(libpath), "-ljsorb",
+                           "-lpthread", "-Wl,-rpath," + os.path.dirname(libpath), "-o", exe])
+    assert os.path.exists(exe)
+
+
 def test_cpp_syncedmem_example_compiles_and_links(libpath, tmp_path):
     """examples/search_by_projection.cpp: the SyncedMem<T> call pattern of ORBmatcher.cpp:1673-1773 / Tracking.cpp:1427-1600 (run on the GPU box
     by tests/test_gpu_parity.py::test_cpp_syncedmem_call_pattern_of_orbmatcher_and_tracking)"""
@@ -151,3 +162,7 @@ def test_library_sets_its_hip_runtime_default_and_respects_the_users(libpath):
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "16"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "4"
+    # JSORB_NO_ENV=1: an integrator forbids the library to touch the process environment at all
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["JSORB_NO_ENV"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "unset"

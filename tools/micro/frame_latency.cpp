@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -31,8 +32,16 @@ int main(int argc, char **argv)
     auto imL = read_raw(argv[8], (size_t)H * W), imR = read_raw(argv[9], (size_t)H * W);
     Jetson_SLAM::ORBExtractor exL(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
     Jetson_SLAM::ORBExtractor exR(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
-    orb_cuda::SyncedMem<int> kpL, kpR;
-    orb_cuda::SyncedMem<unsigned char> dL, dR;
+    // The four SyncedMem members of a Frame (Frame.h:234-237).  Default: long-lived objects (what the reference's commented-out static
+    // variant would give).  JSORB_FRESH_SYNCEDMEM=1: constructed anew for every frame and destroyed with it, as the shipped Frame does -
+    // the shim then patches the frame graph's destinations and serves the buffers from its cache (jsorb_compat.hpp).
+    struct FrameMems { orb_cuda::SyncedMem<int> kpL, kpR; orb_cuda::SyncedMem<unsigned char> dL, dR; };
+    const bool fresh = getenv("JSORB_FRESH_SYNCEDMEM") != nullptr;
+    std::unique_ptr<FrameMems> mems(new FrameMems);
+#define kpL mems->kpL
+#define kpR mems->kpR
+#define dL mems->dL
+#define dR mems->dR
     std::vector<float> mvuRight, mvDepth;
     std::vector<jsorb_keypoint> keys, keysR;
     std::vector<unsigned char> desc, descR;
@@ -58,6 +67,7 @@ int main(int argc, char **argv)
     std::vector<double> per_frame;
     for (int it = -20; it < frames; it++) {
         const double t0 = now_us();
+        if (fresh) mems.reset(new FrameMems);         // inside the timed region: it is part of what a frame costs
         if (persistent) {        // what an integrator gains by keeping the two extractor threads alive (not the reference's code shape)
             done.store(0, std::memory_order_relaxed);
             go.fetch_add(1, std::memory_order_release);
