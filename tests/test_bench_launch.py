@@ -48,6 +48,23 @@ def test_bench_launches_two_ranks_itself_and_gathers_counts():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_c4_shape_on_one_device():
+    """BASELINE C4 exactly as the driver's 8-GPU run shapes it - `--gpus 8 --pairs-total 64` on the EuRoC configuration: eight ranks (all
+    on cuda:0 here, collective over gloo) of eight pairs each, global pair sharding, one all_gather per step, every rank checking every
+    row of the gathered table, launch and teardown of eight processes."""
+    args = ["--gpus", "8", "--pairs-total", "64", "--config", "c2", "--steps", "3", "--warmup", "1", "--min-time", "0.05", "--no-cpu-baseline", "--no-extras",
+            "--profile-steps", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_clean_env(JSORB_BENCH_SINGLE_DEVICE="1", JSORB_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["pairs_per_gpu_per_step"] == 8 and d["config"]["pairs_per_step_total"] == 64
+    assert d["parity_vs_oracle"] is True and d["gathered_counts_ok"] is True and d["parity_pairs_checked"] == 64
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     n = torch.cuda.device_count()
