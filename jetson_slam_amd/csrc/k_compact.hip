@@ -19,7 +19,8 @@ __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned lon
     const int b = blockIdx.x;
     const unsigned long long *tin = tile_out + (size_t)b * g.T;
     unsigned long long *kout = kp + (size_t)b * g.T;
-    int *rt = row_tab + (size_t)b * g.row_tab_len;
+    int *rt = row_tab + (size_t)b * g.row_tab_stride;
+    int *tp = rt + g.row_tab_len;                              // per-tile start table: index of the first keypoint at or after tile j (T + 1 entries)
     int base = 0;
     for (int lvl = 0; lvl < g.L; lvl++) {
         const LevelDesc &lv = g.lv[lvl];
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned lon
             }
             const int pos = base + wbase + wpre;
             if (flag) kout[pos] = p | ((unsigned long long)lvl << 44);
+            if (j < n) tp[lv.tile_off + j] = pos;
             if (j < n && (j % lv.ntw) == 0) rt[lv.row_tab_off + j / lv.ntw] = pos;
             base += tot;
             __syncthreads();
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(1024) void k_compact(Geometry g, const unsigned lon
         }
     }
     if (tid == 0) {
+        tp[g.T] = base;
         counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = base;
         if (counts_host) counts_host[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = base;
     }
@@ -83,7 +86,8 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     const int b = blockIdx.x, T = g.T;
     const unsigned long long *tin = tile_out + (size_t)b * T;
     unsigned long long *kout = kp + (size_t)b * T;
-    int *rt = row_tab + (size_t)b * g.row_tab_len;
+    int *rt = row_tab + (size_t)b * g.row_tab_stride;
+    int *tp = rt + g.row_tab_len;                              // per-tile start table: index of the first keypoint at or after tile j (T + 1 entries)
     const int n_chunks = (T + 1023) >> 10, n_cells = n_chunks * 16;
     for (int c = 0; c < n_chunks; c++) {
         const int j = c * 1024 + tid;
@@ -121,6 +125,8 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
             kout[compact_pos_of(j, T, total, s_bal, s_base)] = p | ((unsigned long long)lvl << 44);
         }
     }
+    // first keypoint at or after every tile (the stereo matcher's column pruning)
+    for (int t = tid; t <= T; t += 1024) tp[t] = compact_pos_of(t, T, total, s_bal, s_base);
     // first keypoint of every tile row (+ the end of each level), per-level counts
     for (int t = tid; t < g.row_tab_len; t += 1024) {
         int lvl = 0;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
                                                unsigned *__restrict__ aux, StereoArgs sa, int n_pairs)
 {
-    __shared__ int s_lvi[JSORB_MAX_LEVELS][8];       // th, nth, row_tab_off, W, pitch, img_off, 1/th magic (per level, lane-indexable)
+    __shared__ int s_lvi[JSORB_MAX_LEVELS][12];      // th, nth, row_tab_off, W, pitch, img_off, 1/th magic, tw, ntw, tile_off, 1/tw magic (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
     const int lane = threadIdx.x;
     const int grp = lane / SGL, sl = lane % SGL;
@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         s_lvi[lane][0] = lv.th; s_lvi[lane][1] = lv.nth; s_lvi[lane][2] = lv.row_tab_off; s_lvi[lane][3] = lv.W;
         s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
         s_lvi[lane][6] = (int)(0xFFFFFFFFu / (unsigned)lv.th + 1u);      // x / th == umulhi(x, magic) for x < 2^16, th > 1
+        s_lvi[lane][7] = lv.tw; s_lvi[lane][8] = lv.ntw; s_lvi[lane][9] = lv.tile_off;
+        s_lvi[lane][10] = (int)(0xFFFFFFFFu / (unsigned)lv.tw + 1u);
         s_lvf[lane][0] = lv.scale; s_lvf[lane][1] = lv.inv_scale;
     }
     wave_lds_sync_st();
@@ -82,13 +84,15 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         const uint4 *dl = reinterpret_cast<const uint4 *>(descL + (tb + i) * 32);
         const uint4 a0 = dl[0], a1 = dl[1];
         const int vLi = (int)vL;
-        const int *rt = row_tabR + (size_t)b * g.row_tab_len;
+        const int *rt = row_tabR + (size_t)b * g.row_tab_stride;
         int j0[3], len[3];
+        int nrw[3], tl0[3], tst[3], ncl[3];      // column-pruned form: tile rows of the band, tile index of (first row, first column), tiles per row, columns of the window
         float rr[3];
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int lr = levelL - 1 + t;
             j0[t] = 0; len[t] = 0; rr[t] = 0.f;
+            nrw[t] = 0; tl0[t] = 0; tst[t] = 0; ncl[t] = 0;
             if (lr >= 0 && lr < g.L && !(maxU < 0)) {
                 const float scl = s_lvf[lr][0], iscl = s_lvf[lr][1];
                 const int th = s_lvi[lr][0], nth = s_lvi[lr][1], rto = s_lvi[lr][2];
@@ -103,28 +107,80 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                 int t_hi = hi < 0 ? -1 : (th > 1 ? (int)__umulhi((unsigned)hi, th_magic) : hi);
                 if (t_hi > nth - 1) t_hi = nth - 1;
                 if (t_lo <= t_hi) {
-                    j0[t] = rt[rto + t_lo];
-                    len[t] = rt[rto + t_hi + 1] - j0[t];
+                    if (!g.stereo_colprune) {
+                        j0[t] = rt[rto + t_lo];
+                        len[t] = rt[rto + t_hi + 1] - j0[t];
+                    } else {
+                        const int tw = s_lvi[lr][7], ntw = s_lvi[lr][8];
+                        const unsigned tw_magic = (unsigned)s_lvi[lr][10];
+                        const int xlo = (int)__builtin_floorf((minU - 1.0f) * iscl) - 1, xhi = (int)__builtin_ceilf((maxU + 1.0f) * iscl) + 1;
+                        const int c_lo = xlo < 0 ? 0 : (tw > 1 ? (int)__umulhi((unsigned)xlo, tw_magic) : xlo);
+                        int c_hi = xhi < 0 ? -1 : (tw > 1 ? (int)__umulhi((unsigned)xhi, tw_magic) : xhi);
+                        if (c_hi > ntw - 1) c_hi = ntw - 1;
+                        if (c_lo <= c_hi) {
+                            nrw[t] = t_hi - t_lo + 1;
+                            tl0[t] = s_lvi[lr][9] + t_lo * ntw + c_lo;
+                            tst[t] = ntw;
+                            ncl[t] = c_hi - c_lo + 1;
+                        }
+                    }
                 }
             }
         }
-        const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
-        for (int k = sl; k < total; k += SGL) {
-            const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
-            const int j = (t == 2 ? j0[2] - c2 : (t == 1 ? j0[1] - c1 : j0[0])) + k;
-            const float r = t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]);
+        // one right keypoint against this left keypoint: the reference's exact row / column tests, then the Hamming distance
+        auto candidate = [&](int j, float r) {
             const float kpY = (float)oR[Nr + j];
             const float uR = (float)oR[j];
             const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + j) * 32);
             const uint4 b0 = dr[0], b1 = dr[1];
             const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
-            if (vLi < minr || vLi > maxr) continue;
-            if (!(uR >= minU && uR <= maxU)) continue;
+            if (vLi < minr || vLi > maxr) return;
+            if (!(uR >= minU && uR <= maxU)) return;
             n_cand++;
             const int d = hamming256(a0, a1, b0, b1);
             if (d < sa.th_high) {
                 const unsigned key = ((unsigned)d << 20) | (unsigned)j;
                 best_key = key < best_key ? key : best_key;
+            }
+        };
+        if (!g.stereo_colprune) {
+            const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
+            for (int k = sl; k < total; k += SGL) {
+                const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
+                const int j = (t == 2 ? j0[2] - c2 : (t == 1 ? j0[1] - c1 : j0[0])) + k;
+                candidate(j, t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]));
+            }
+        } else {
+            // Column pruning: the keypoints of a tile row are ordered by tile column (one per tile at most), so those inside the disparity
+            // window [uL - maxD, uL] sit in a contiguous run of tiles.  Every (level, tile row) of the band becomes a SEGMENT
+            // [tile_pos[row, c_lo], tile_pos[row, c_hi + 1]) of the right image's keypoint list (per-tile start table of k_compact); lane s of
+            // the group fetches segment s (one round trip for all of them), then the group walks the segments.  At 64 tiles per row and a
+            // window of 23 tiles this scans a third of what the whole-row form scans.  The window is conservative by a pixel on each side
+            // (a keypoint's level-0 x is int(x_level * scale)); the exact tests above decide.
+            const int *tp = rt + g.row_tab_len;
+            const int c1 = nrw[0], c2 = nrw[0] + nrw[1], nseg = c2 + nrw[2];
+            int nseg_max = nseg;                         // largest segment count of the wave's four keypoints (wave-uniform)
+            nseg_max = max(max(__builtin_amdgcn_readlane(nseg, 0), __builtin_amdgcn_readlane(nseg, 16)),
+                           max(__builtin_amdgcn_readlane(nseg, 32), __builtin_amdgcn_readlane(nseg, 48)));
+            for (int s0 = 0; s0 < nseg_max; s0 += SGL) {
+                const int sg = s0 + sl;
+                int seg_start = 0, seg_len = 0;
+                float seg_r = 0.f;
+                if (sg < nseg) {
+                    const int t = sg >= c2 ? 2 : (sg >= c1 ? 1 : 0);
+                    const int row = sg - (t == 2 ? c2 : (t == 1 ? c1 : 0));
+                    const int tile = (t == 2 ? tl0[2] : (t == 1 ? tl0[1] : tl0[0])) + row * (t == 2 ? tst[2] : (t == 1 ? tst[1] : tst[0]));
+                    seg_start = tp[tile];
+                    seg_len = tp[tile + (t == 2 ? ncl[2] : (t == 1 ? ncl[1] : ncl[0]))] - seg_start;
+                    seg_r = t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]);
+                }
+                const int n_here = min(SGL, nseg_max - s0);
+                for (int q = 0; q < n_here; q++) {
+                    const int src_lane = (lane & ~(SGL - 1)) + q;
+                    const int st = __shfl(seg_start, src_lane, 64), ln = __shfl(seg_len, src_lane, 64);
+                    const float r = __shfl(seg_r, src_lane, 64);
+                    for (int k = sl; k < ln; k += SGL) candidate(st + k, r);
+                }
             }
         }
     }
