@@ -506,13 +506,13 @@ def measure_copy_peak(torch, dev, gib=1.0, reps=6):
 
 def valu_view(config, pairs_per_s, n_cus, clock_hz):
     """What actually bounds the path: vector-ALU issue.  SQ_INSTS_VALU per kernel launch comes from the builder's rocprofv3 PMC pass
-    (profiles/valu_counters.json, condensed from profiles/r03_sq_counters.csv: 128 images per extract-side launch, 128 pairs per
-    stereo-side launch) - NOT measured in this run; a SIMD issues at most one VALU wave-instruction per 4 clocks."""
+    (profiles/valu_counters.json, condensed from profiles/r03_sq_counters*.csv) - NOT measured in this run; a SIMD issues at most one
+    VALU wave-instruction per 4 clocks."""
     path = os.path.join(ROOT, "profiles", "valu_counters.json")
     try:
         tj = json.load(open(path))
         k = tj[config]
-        per_pair = (2.0 * sum(v for n, v in k["extract_side"].items()) + sum(v for n, v in k["stereo_side"].items())) / float(tj["_pairs_per_launch"])
+        per_pair = (2.0 * sum(v for n, v in k["extract_side"].items()) + sum(v for n, v in k["stereo_side"].items())) / float(k["_pairs_per_launch"])
         peak = n_cus * 4 * clock_hz / 4.0                     # VALU wave-instructions per second the chip can issue
         return {"valu_wave_instr_per_pair": round(per_pair), "valu_wave_instr_per_128_pairs": round(per_pair * 128),
                 "valu_issue_frac": round(per_pair * pairs_per_s / peak, 4),
@@ -596,6 +596,20 @@ def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seco
            "algo_bytes_per_pair": ab, "pipeline_frac": round(ab * pps / 1e9 / HBM_PEAK_GBS, 4),
            "kernel": dom, "frac": round(ab * units / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4),
            "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()}}
+    if not tile_override:
+        props = torch.cuda.get_device_properties(dev)
+        vv = valu_view(name, pps, props.multi_processor_count, 2.4e9)
+        if vv:
+            out["valu_issue_frac"] = vv["valu_issue_frac"]
+            out["valu_wave_instr_per_pair"] = vv["valu_wave_instr_per_pair"]
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            kname = "k_compact_flat" if dom == "k_compact" else dom
+            out["traffic"] = tj.get(name, {}).get(kname)
+            out["traffic_note"] = "bytes per launch of %d %s, builder-measured rocprofv3 PMC pass (profiles/r03_hbm_traffic.json), NOT measured in this run" % (
+                P, "pairs" if dom in ("k_stereo", "k_median") else "images")
+        except Exception:
+            pass
     a.close(); b.close()
     return out
 

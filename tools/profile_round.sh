@@ -7,11 +7,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-B="python $ROOT/bench.py --steps 10 --warmup 2 --min-time 0 --no-cpu-baseline --no-extras --profile-steps 0 --single-stream"   # one stream: per-kernel durations are not inflated by left/right overlap
+# PROFILE_ARGS="--config c3 --pairs 64" profiles another configuration (no bench line then); tag it e.g. r03c3
+if [ -z "$PROFILE_ARGS" ]; then python $ROOT/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; fi
+B="python $ROOT/bench.py --steps 10 --warmup 2 --min-time 0 --no-cpu-baseline --no-extras --profile-steps 0 --single-stream $PROFILE_ARGS"   # one stream: per-kernel durations are not inflated by left/right overlap
 rm -rf $O/${TAG}_trace $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o t -- $B > $O/${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -o p -- $B > $O/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_write -o p -- $B > $O/${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/${TAG}_sq -o p -- $B > $O/${TAG}_sq.log 2>&1
-python $ROOT/tools/profile_summary.py $TAG
+python $ROOT/tools/profile_summary.py $TAG ${PROFILE_CONFIG:-}
