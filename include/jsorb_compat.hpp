@@ -60,10 +60,10 @@ struct SyncedBufferCache {
         }
         return jsorb_mem_stream_create(st);
     }
-    void give_stream(cudaStream_t st)
+    void give_stream(cudaStream_t st, bool used)
     {
         if (!st) return;
-        jsorb_mem_stream_sync(st);
+        if (used) jsorb_mem_stream_sync(st);       // a stream that never carried work needs no wait (hipStreamSynchronize is ~5 us, four per Frame)
         {
             std::lock_guard<std::mutex> lk(mu);
             if (free_streams.size() < 64) { free_streams.push_back(st); return; }
@@ -108,7 +108,7 @@ struct SyncedBufferCache {
 // original (a reference count decides who frees); an object that has to grow while it shares leaves the old buffers to the others.
 template <typename Dtype>
 class SyncedMem {
-    struct Owner { void *cpu = nullptr, *gpu = nullptr; cudaStream_t stream = nullptr; size_t bytes = 0; bool pitched = false; std::atomic<int> refs{1}; };
+    struct Owner { void *cpu = nullptr, *gpu = nullptr; cudaStream_t stream = nullptr; size_t bytes = 0; bool pitched = false; std::atomic<bool> stream_used{false}; std::atomic<int> refs{1}; };
 
 public:
     SyncedMem() : count_(0), capacity_(0), cpu_data_(nullptr), gpu_data_(nullptr), pitch_(0), cu_stream_(nullptr), cu_error_(0), own_(new Owner)
@@ -199,16 +199,18 @@ public:
     void to_cpu_async(cudaStream_t &cu_stream, int count)
     {
         if (host_fresh_ && count <= count_) return;
+        mark_stream(cu_stream);
         note(jsorb_mem_d2h_async(cpu_data_, gpu_data_, (size_t)count * sizeof(Dtype), cu_stream));
     }
     void to_gpu_async(cudaStream_t &cu_stream, int count)
     {
         host_fresh_ = false;
+        mark_stream(cu_stream);
         note(jsorb_mem_h2d_async(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype), cu_stream));
     }
     void sync_stream(void) { note(jsorb_mem_stream_sync(cu_stream_)); }
     void set_zero_gpu(void) { host_fresh_ = false; note(jsorb_mem_set_zero(gpu_data_, (size_t)count_ * sizeof(Dtype))); }
-    void set_zero_gpu_async(void) { host_fresh_ = false; note(jsorb_mem_set_zero_async(gpu_data_, (size_t)count_ * sizeof(Dtype), cu_stream_)); }
+    void set_zero_gpu_async(void) { host_fresh_ = false; mark_stream(cu_stream_); note(jsorb_mem_set_zero_async(gpu_data_, (size_t)count_ * sizeof(Dtype), cu_stream_)); }
     void set_zero_cpu(void) { host_fresh_ = false; if (cpu_data_) memset(cpu_data_, 0, (size_t)count_ * sizeof(Dtype)); }
 
     // public in the reference ("//private:" is commented out there)
@@ -227,9 +229,12 @@ public:
 private:
     Owner *own_;
     void note(int rc) { if (rc != JSORB_OK) cu_error_ = rc; }
+    // work enqueued on any stream makes the buffers busy until that stream has run: the release paths wait for the private stream only when it was
+    // used (work put on a FOREIGN stream is the caller's to synchronise before the object goes away, as in the reference)
+    void mark_stream(cudaStream_t st) { if (own_ && st == own_->stream) own_->stream_used.store(true); }
     static void destroy(Owner *o)
     {
-        detail::SyncedBufferCache::get().give_stream(o->stream);      // (waits for the stream's work first)
+        detail::SyncedBufferCache::get().give_stream(o->stream, o->stream_used.load());      // (waits for the stream's work first, if it ever had any)
         if (o->pitched) { if (o->cpu) jsorb_mem_free_host(o->cpu); if (o->gpu) jsorb_mem_free_device(o->gpu); }
         else if (o->cpu || o->gpu) detail::SyncedBufferCache::get().give(o->bytes, o->cpu, o->gpu);
         delete o;
@@ -246,7 +251,7 @@ private:
         if (own_ && own_->refs.load() == 1) {
             if (own_->pitched) { if (own_->cpu) jsorb_mem_free_host(own_->cpu); if (own_->gpu) jsorb_mem_free_device(own_->gpu); }
             else if (own_->cpu || own_->gpu) {
-                if (own_->stream) jsorb_mem_stream_sync(own_->stream);
+                if (own_->stream && own_->stream_used.load()) jsorb_mem_stream_sync(own_->stream);
                 detail::SyncedBufferCache::get().give(own_->bytes, own_->cpu, own_->gpu);
             }
             own_->cpu = own_->gpu = nullptr;
