@@ -275,6 +275,18 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
     // JSORB_STEREO_COLPRUNE=0 restores the whole-row scan.
     g.stereo_colprune = 1;
     if (const char *cp = getenv("JSORB_STEREO_COLPRUNE")) g.stereo_colprune = atoi(cp) != 0;
+    // Scan-line buckets (k_compact sorts the keypoints by level and level-0 row, k_stereo scans the few buckets around the left keypoint's
+    // row instead of whole tile rows): 370 -> 35 right keypoints looked at per left keypoint at the EuRoC shape.  Needs the flat k_compact
+    // (T <= 65536), L * H0 counters in its LDS, and level-0 coordinates that fit 16 bits.  JSORB_STEREO_EPI=0 keeps the tile-based scan.
+    g.epi_rows = 0; g.epi_off = 0;
+    {
+        const bool want = !(getenv("JSORB_STEREO_EPI") && atoi(getenv("JSORB_STEREO_EPI")) == 0);
+        if (want && tiles <= 65536 && g.L * g.lv[0].H <= 12288 && g.lv[0].W < 32768 && g.lv[0].H < 32768) {
+            g.epi_rows = g.lv[0].H;
+            g.epi_off = (g.row_tab_stride + 1) & ~1;
+            g.row_tab_stride = g.epi_off + ((g.L * g.epi_rows + 2) & ~1) + 2 * tiles;
+        }
+    }
     g.slab_bytes = off;
     fill_pyramid_layout(g);              // k_pyramid: PYR_TW x pyr_th output tile per (single-wave) workgroup
     return JSORB_OK;

@@ -5,7 +5,15 @@
 // ballot/popcount prefix inside each wave and a 16-entry LDS scan across the waves.  Output order is identical
 // to the CPU loop: level-major, tile-raster within a level, candidates with score > 0 only.
 // Besides the compacted list it emits per-level counts (n_keypoints_[i]) and, for the stereo matcher, the index
-// of the first keypoint of every tile row (keypoints of one tile row are contiguous in the output).
+// of the first keypoint of every tile row (keypoints of one tile row are contiguous in the output) and of every tile, and
+// (flat form) the keypoints counting-sorted by (level, level-0 row): the matcher's scan-line buckets.
+//
+// Scan-line buckets.  The reference builds vRowIndices on the CPU: right keypoint iR is listed under every row of
+// [floor(y - r), ceil(y + r)], r = 2 * scale[octave] (orb_stereo_match.cu:119-140), and a left keypoint looks at the list of its
+// row.  Here every keypoint is listed ONCE, under (level, its level-0 row): the keypoints of level l that cover row v have their
+// row in (v - 1 - r_l, v + 1 + r_l), a contiguous run of buckets of that level, which k_stereo reads off the start table and
+// filters with the reference's exact tests.  Two LDS atomics per keypoint instead of one per covered row; the order inside a
+// bucket is whatever the atomics give - the matcher's (distance, iR) min-key does not depend on it.
 #include "jsorb_launch.h"
 
 namespace jsorb {
@@ -82,8 +90,13 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     __shared__ int s_base[CMP_MAX_CHUNKS * 16];
     __shared__ int s_wtot[16];
     __shared__ int s_total;
+    __shared__ float s_scale[JSORB_MAX_LEVELS];
+    extern __shared__ int s_epi[];                             // L * epi_rows bucket counters (scan-line buckets), then cursors
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);
     const int b = blockIdx.x, T = g.T;
+    const int EH = g.epi_rows, EN = g.L * EH;
+    for (int t = tid; t < EN; t += 1024) s_epi[t] = 0;
+    if (tid < g.L) s_scale[tid] = g.lv[tid].scale;
     const unsigned long long *tin = tile_out + (size_t)b * T;
     unsigned long long *kout = kp + (size_t)b * T;
     int *rt = row_tab + (size_t)b * g.row_tab_stride;
@@ -123,6 +136,7 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
             for (int i = 1; i < g.L; i++)
                 if (j >= g.lv[i].tile_off) lvl = i;
             kout[compact_pos_of(j, T, total, s_bal, s_base)] = p | ((unsigned long long)lvl << 44);
+            if (EN) atomicAdd(&s_epi[lvl * EH + min((int)((float)kp_y(p) * s_scale[lvl]), EH - 1)], 1);
         }
     }
     // first keypoint at or after every tile (the stereo matcher's column pruning)
@@ -147,13 +161,56 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
         counts[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = total;
         if (counts_host) counts_host[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS] = total;
     }
+    if (!EN) return;
+    // ---- scan-line buckets: exclusive scan of the bucket counts (a contiguous run per thread), then the scatter ----
+    int *et = rt + g.epi_off;                                  // EN + 1 bucket starts, then the entries
+    int2 *ee = reinterpret_cast<int2 *>(et + ((EN + 2) & ~1));
+    __syncthreads();
+    {
+        const int per = (EN + 1023) >> 10, t0 = tid * per, t1 = min(t0 + per, EN);
+        int sum = 0;
+        for (int t = t0; t < t1; t++) sum += s_epi[t];
+        const int incl = wave_inclusive_scan_i32(sum);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            if (w < wave) base += s_wtot[w];
+        int run = base + incl - sum;
+        for (int t = t0; t < t1; t++) {
+            const int c = s_epi[t];
+            s_epi[t] = run;
+            et[t] = run;
+            run += c;
+        }
+        if (tid == 0) et[EN] = total;
+    }
+    __syncthreads();
+    // dense pass over the compacted list this workgroup has just written (level in the record, scale from LDS): four independent
+    // records per thread and round, so that their load latencies overlap - the kernel is one workgroup per image and pure latency
+    for (int i0 = tid; i0 < total; i0 += 4096) {
+        unsigned long long p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = i0 + 1024 * u < total ? kout[i0 + 1024 * u] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + 1024 * u >= total) break;
+            const int lvl = kp_level(p[u]);
+            const float sc = s_scale[lvl];
+            const int yi = (int)((float)kp_y(p[u]) * sc), xi = (int)((float)kp_x(p[u]) * sc);      // the level-0 coordinates k_describe packs (K11)
+            const int slot = atomicAdd(&s_epi[lvl * EH + min(yi, EH - 1)], 1);
+            ee[slot] = make_int2(i0 + 1024 * u, (xi & 0xFFFF) | (yi << 16));
+        }
+    }
 }
 
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s, int *counts_host)
 {
     if (g.T <= CMP_MAX_CHUNKS * 1024)
-        hipLaunchKernelGGL(k_compact_flat, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab, counts_host);
+        hipLaunchKernelGGL(k_compact_flat, dim3(n_images), dim3(1024), g.epi_rows ? (size_t)g.L * g.epi_rows * sizeof(int) : 0, s, g, tile_out, kp, counts,
+                           row_tab, counts_host);
     else
         hipLaunchKernelGGL(k_compact, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab, counts_host);
 }

@@ -60,11 +60,13 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
     if (blk * SKPW >= Nl) return;                     // whole wave idle
     if (lane < g.L) {
         const LevelDesc &lv = g.lv[lane];
-        s_lvi[lane][0] = lv.th; s_lvi[lane][1] = lv.nth; s_lvi[lane][2] = lv.row_tab_off; s_lvi[lane][3] = lv.W;
-        s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
-        s_lvi[lane][6] = (int)(0xFFFFFFFFu / (unsigned)lv.th + 1u);      // x / th == umulhi(x, magic) for x < 2^16, th > 1
-        s_lvi[lane][7] = lv.tw; s_lvi[lane][8] = lv.ntw; s_lvi[lane][9] = lv.tile_off;
-        s_lvi[lane][10] = (int)(0xFFFFFFFFu / (unsigned)lv.tw + 1u);
+        s_lvi[lane][3] = lv.W; s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
+        if (!g.epi_rows) {                           // the tile-based candidate windows only
+            s_lvi[lane][0] = lv.th; s_lvi[lane][1] = lv.nth; s_lvi[lane][2] = lv.row_tab_off;
+            s_lvi[lane][6] = (int)(0xFFFFFFFFu / (unsigned)lv.th + 1u);      // x / th == umulhi(x, magic) for x < 2^16, th > 1
+            s_lvi[lane][7] = lv.tw; s_lvi[lane][8] = lv.ntw; s_lvi[lane][9] = lv.tile_off;
+            s_lvi[lane][10] = (int)(0xFFFFFFFFu / (unsigned)lv.tw + 1u);
+        }
         s_lvf[lane][0] = lv.scale; s_lvf[lane][1] = lv.inv_scale;
     }
     wave_lds_sync_st();
@@ -85,6 +87,47 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         const uint4 a0 = dl[0], a1 = dl[1];
         const int vLi = (int)vL;
         const int *rt = row_tabR + (size_t)b * g.row_tab_stride;
+        if (g.epi_rows) {
+            // Scan-line buckets (k_compact): the right keypoints of level lr that cover row vL have their own row in
+            // (vL - 1 - r, vL + 1 + r), r = 2 * scale[lr]: a contiguous run of that level's row buckets (one more row on each side against
+            // the rounding of the float sums; the reference's exact tests decide).  Lane t < 3 of the group fetches the run of level
+            // levelL - 1 + t, the three runs are walked as one flat index space: 16 entries of 8 bytes per step, coalesced.
+            const int EH = g.epi_rows, EN = g.L * EH;
+            const int *et = rt + g.epi_off;
+            const int2 *ee = reinterpret_cast<const int2 *>(et + ((EN + 2) & ~1));
+            int seg_start = 0, seg_len = 0;
+            {
+                const int lr = levelL - 1 + sl;
+                if (sl < 3 && lr >= 0 && lr < g.L && !(maxU < 0)) {
+                    const float r = 2.0f * s_lvf[lr][0];
+                    const int ylo = max((int)__builtin_floorf((float)vLi - 2.0f - r), 0), yhi = min((int)__builtin_ceilf((float)vLi + 2.0f + r), EH - 1);
+                    if (ylo <= yhi) {
+                        seg_start = et[lr * EH + ylo];
+                        seg_len = et[lr * EH + yhi + 1] - seg_start;
+                    }
+                }
+            }
+            const int gl0 = lane & ~(SGL - 1);
+            const int st0 = __shfl(seg_start, gl0, 64), st1 = __shfl(seg_start, gl0 + 1, 64), st2 = __shfl(seg_start, gl0 + 2, 64);
+            const int c1 = __shfl(seg_len, gl0, 64), c2 = c1 + __shfl(seg_len, gl0 + 1, 64), total = c2 + __shfl(seg_len, gl0 + 2, 64);
+            const float r0 = 2.0f * s_lvf[max(levelL - 1, 0)][0], r1 = 2.0f * s_lvf[levelL][0], r2 = 2.0f * s_lvf[min(levelL + 1, g.L - 1)][0];
+            for (int k = sl; k < total; k += SGL) {
+                const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
+                const int2 e = ee[(t == 2 ? st2 - c2 : (t == 1 ? st1 - c1 : st0)) + k];
+                const float kpY = (float)((unsigned)e.y >> 16), uR = (float)(e.y & 0xFFFF);
+                const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + e.x) * 32);
+                const float r = t == 2 ? r2 : (t == 1 ? r1 : r0);
+                const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
+                if (vLi < minr || vLi > maxr) continue;
+                if (!(uR >= minU && uR <= maxU)) continue;
+                n_cand++;
+                const int d = hamming256(a0, a1, dr[0], dr[1]);
+                if (d < sa.th_high) {
+                    const unsigned key = ((unsigned)d << 20) | (unsigned)e.x;
+                    best_key = key < best_key ? key : best_key;
+                }
+            }
+        } else {
         int j0[3], len[3];
         int nrw[3], tl0[3], tst[3], ncl[3];      // column-pruned form: tile rows of the band, tile index of (first row, first column), tiles per row, columns of the window
         float rr[3];
@@ -128,9 +171,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             }
         }
         // one right keypoint against this left keypoint: the reference's exact row / column tests, then the Hamming distance
-        auto candidate = [&](int j, float r) {
-            const float kpY = (float)oR[Nr + j];
-            const float uR = (float)oR[j];
+        auto candidate_at = [&](int j, float kpY, float uR, float r) {
             const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + j) * 32);
             const uint4 b0 = dr[0], b1 = dr[1];
             const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
@@ -143,6 +184,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                 best_key = key < best_key ? key : best_key;
             }
         };
+        auto candidate = [&](int j, float r) { candidate_at(j, (float)oR[Nr + j], (float)oR[j], r); };
         if (!g.stereo_colprune) {
             const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
             for (int k = sl; k < total; k += SGL) {
@@ -182,6 +224,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                     for (int k = sl; k < ln; k += SGL) candidate(st + k, r);
                 }
             }
+        }
         }
     }
     static_assert(SGL == 16, "the lane group of a keypoint is one DPP row");
