@@ -91,12 +91,16 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     __shared__ int s_wtot[16];
     __shared__ int s_total;
     __shared__ float s_scale[JSORB_MAX_LEVELS];
+    __shared__ int s_toff[JSORB_MAX_LEVELS];                   // first tile of every level (a loop over the kernel arguments paid a scalar-load round trip per level and candidate)
     extern __shared__ int s_epi[];                             // L * epi_rows bucket counters (scan-line buckets), then cursors
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);
     const int b = blockIdx.x, T = g.T;
     const int EH = g.epi_rows, EN = g.L * EH;
     for (int t = tid; t < EN; t += 1024) s_epi[t] = 0;
-    if (tid < g.L) s_scale[tid] = g.lv[tid].scale;
+    if (tid < JSORB_MAX_LEVELS) {
+        s_scale[tid] = tid < g.L ? g.lv[tid].scale : 0.0f;
+        s_toff[tid] = tid < g.L ? g.lv[tid].tile_off : 0x7FFFFFFF;
+    }
     const unsigned long long *tin = tile_out + (size_t)b * T;
     unsigned long long *kout = kp + (size_t)b * T;
     int *rt = row_tab + (size_t)b * g.row_tab_stride;
@@ -132,9 +136,8 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
         const unsigned long long p = tin[j];
         if (kp_score(p) > 0) {
             int lvl = 0;
-#pragma unroll 1
-            for (int i = 1; i < g.L; i++)
-                if (j >= g.lv[i].tile_off) lvl = i;
+#pragma unroll
+            for (int i = 1; i < JSORB_MAX_LEVELS; i++) lvl += j >= s_toff[i] ? 1 : 0;
             kout[compact_pos_of(j, T, total, s_bal, s_base)] = p | ((unsigned long long)lvl << 44);
             if (EN) atomicAdd(&s_epi[lvl * EH + min((int)((float)kp_y(p) * s_scale[lvl]), EH - 1)], 1);
         }
