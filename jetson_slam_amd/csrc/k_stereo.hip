@@ -88,10 +88,12 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         const int vLi = (int)vL;
         const int *rt = row_tabR + (size_t)b * g.row_tab_stride;
         if (g.epi_rows) {
-            // Scan-line buckets (k_compact): the right keypoints of level lr that cover row vL have their own row in
-            // (vL - 1 - r, vL + 1 + r), r = 2 * scale[lr]: a contiguous run of that level's row buckets (one more row on each side against
-            // the rounding of the float sums; the reference's exact tests decide).  Lane t < 3 of the group fetches the run of level
-            // levelL - 1 + t, the three runs are walked as one flat index space: 16 entries of 8 bytes per step, coalesced.
+            // Scan-line buckets (k_compact): a right keypoint of level lr in row y (its level-0 row, an integer) covers row vL iff
+            // floor(y - r) <= vL <= ceil(y + r), r = 2 * scale[lr], both evaluated in f32 as the reference does.  Both bounds are
+            // non-decreasing in y, so the rows that pass form ONE run [first, last] of that level's buckets: it is found exactly here,
+            // once per level (lane t < 3 of the group takes level levelL - 1 + t and walks in from a bound that is two rows too wide on
+            // each side), and the candidates need no row test of their own.  The three runs are then walked as one flat index space:
+            // 16 entries of 8 bytes per step, coalesced.
             const int EH = g.epi_rows, EN = g.L * EH;
             const int *et = rt + g.epi_off;
             const int2 *ee = reinterpret_cast<const int2 *>(et + ((EN + 2) & ~1));
@@ -99,8 +101,15 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             {
                 const int lr = levelL - 1 + sl;
                 if (sl < 3 && lr >= 0 && lr < g.L && !(maxU < 0)) {
-                    const float r = 2.0f * s_lvf[lr][0];
-                    const int ylo = max((int)__builtin_floorf((float)vLi - 2.0f - r), 0), yhi = min((int)__builtin_ceilf((float)vLi + 2.0f + r), EH - 1);
+                    const float r = 2.0f * s_lvf[lr][0], vLf = (float)vLi;
+                    const float lo_f = __builtin_floorf(vLf - 2.0f - r), hi_f = __builtin_ceilf(vLf + 2.0f + r);
+                    int below = 0, above = 0;                 // rows at the low / high end of [lo, hi] that do not cover vL
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        below += __builtin_ceilf((lo_f + (float)k) + r) < vLf ? 1 : 0;
+                        above += __builtin_floorf((hi_f - (float)k) - r) > vLf ? 1 : 0;
+                    }
+                    const int ylo = max((int)lo_f + below, 0), yhi = min((int)hi_f - above, EH - 1);
                     if (ylo <= yhi) {
                         seg_start = et[lr * EH + ylo];
                         seg_len = et[lr * EH + yhi + 1] - seg_start;
@@ -110,18 +119,14 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             const int gl0 = lane & ~(SGL - 1);
             const int st0 = __shfl(seg_start, gl0, 64), st1 = __shfl(seg_start, gl0 + 1, 64), st2 = __shfl(seg_start, gl0 + 2, 64);
             const int c1 = __shfl(seg_len, gl0, 64), c2 = c1 + __shfl(seg_len, gl0 + 1, 64), total = c2 + __shfl(seg_len, gl0 + 2, 64);
-            const float r0 = 2.0f * s_lvf[max(levelL - 1, 0)][0], r1 = 2.0f * s_lvf[levelL][0], r2 = 2.0f * s_lvf[min(levelL + 1, g.L - 1)][0];
             for (int k = sl; k < total; k += SGL) {
-                const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
-                const int2 e = ee[(t == 2 ? st2 - c2 : (t == 1 ? st1 - c1 : st0)) + k];
-                const float kpY = (float)((unsigned)e.y >> 16), uR = (float)(e.y & 0xFFFF);
+                const int2 e = ee[(k >= c2 ? st2 - c2 : (k >= c1 ? st1 - c1 : st0)) + k];
+                const float uR = (float)(e.y & 0xFFFF);
                 const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + e.x) * 32);
-                const float r = t == 2 ? r2 : (t == 1 ? r1 : r0);
-                const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
-                if (vLi < minr || vLi > maxr) continue;
+                const uint4 b0 = dr[0], b1 = dr[1];
                 if (!(uR >= minU && uR <= maxU)) continue;
                 n_cand++;
-                const int d = hamming256(a0, a1, dr[0], dr[1]);
+                const int d = hamming256(a0, a1, b0, b1);
                 if (d < sa.th_high) {
                     const unsigned key = ((unsigned)d << 20) | (unsigned)e.x;
                     best_key = key < best_key ? key : best_key;
@@ -328,10 +333,11 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         }
     }
     if (refine) {
-        int bestDist = 0x7FFFFFFF, bestR = 0;
+        // first minimum of the 11 sums (strict < in ascending order, :491-505) = minimum of the keys (sum << 4 | shift); sums are < 2^16
+        unsigned kmin = ((unsigned)acc[0] << 4);
 #pragma unroll
-        for (int s = 0; s < 11; s++)
-            if (acc[s] < bestDist) { bestDist = acc[s]; bestR = s; }
+        for (int s = 1; s < 11; s++) kmin = min(kmin, ((unsigned)acc[s] << 4) | (unsigned)s);
+        const int bestDist = (int)(kmin >> 4), bestR = (int)(kmin & 15u);
         if (!(bestR == 0 || bestR == 10)) {
             float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
 #pragma unroll
