@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // Phases 1 and 2 share one loop: early-reject steps append to the wave's list; when the list could not take another step (or the
     // wave has done all its rows) the ring test runs on the pending entries [n_pos, n_mine) and leaves only positives [0, n_pos).
     const int lx_off = c0;
+    const unsigned char *const lane_img = s_img + sub * S + 4 * qq;                      // the lane's dword in image row `sub` of the LDS tile
+    const int ry_lo = max(0, JSORB_BORDER - (y0 - 1)), ry_hi = min(L.score_rows - 1, H - JSORB_BORDER - 1 - (y0 - 1));      // region rows inside the image's interior (wave-uniform)
+    const int e_lane = (sub << 8) + (cb - c0);                                           // list entry of the lane's first pixel in row `sub`
     const int min_pop = g.lut_min_pop;
     const int flush_at = L.list_cap - DET_LIST_STEP;      // wave-uniform; never exceeded when the list holds the worst case
     int n_pos = 0;                                        // wave-uniform: positives at the front of the list
@@ -294,11 +297,11 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
                         unsigned sad = 0;
 #pragma unroll
                         for (int k = 0; k < 8; k++) sad = __builtin_amdgcn_sad_u16(P[k], v2, sad);
-                        s_score[ry * L.score_w + rx] = (unsigned short)sad;
+                        s_score[__umul24(ry, L.score_w) + rx] = (unsigned short)sad;
                     }
                 }
                 const unsigned long long bal = __ballot(hit);
-                if (hit && !dense) my_list[n_pos + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                if (hit && !dense) (my_list + n_pos)[__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
                 n_pos += __popcll(bal);
             }
             if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
@@ -308,13 +311,14 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         // a step whose rows all lie in the image's 20-pixel border (or below the band) has no pixel to test: 12 % of the steps at the
         // EuRoC geometry, 30 % of the rows of the smallest level (wave-uniform: rbase and y0 live in SGPRs)
         if (y0 - 1 + rbase + rows_per_step - 1 < JSORB_BORDER || y0 - 1 + rbase >= H - JSORB_BORDER) continue;
+        // (per step and lane: one address addition - the step's row offset is scalar, the lane's part loop-invariant - and two compares
+        // against the band's valid rows; a row past the region reads the LDS bytes behind the image rows and is masked off below)
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
-        const bool row_ok = ry < L.score_rows && y >= JSORB_BORDER && y < H - JSORB_BORDER;
-        const int rr = row_ok ? ry : 0;
-        const unsigned *rowp = reinterpret_cast<const unsigned *>(s_img + (rr + 3) * S);
-        const unsigned Dm = rowp[qq - 1], D0 = rowp[qq], Dp = rowp[qq + 1];
-        const unsigned Du = rowp[qq - 3 * (S >> 2)], Dd = rowp[qq + 3 * (S >> 2)];
+        const bool row_ok = ry >= ry_lo && ry <= ry_hi;
+        const unsigned *rowp = reinterpret_cast<const unsigned *>(lane_img + (rbase + 3) * S);
+        const unsigned Dm = rowp[-1], D0 = rowp[0], Dp = rowp[1];
+        const unsigned Du = rowp[-3 * (S >> 2)], Dd = rowp[3 * (S >> 2)];
         unsigned okw[2];                                  // sign bits (15 / 31): pixel 2h / 2h+1 survives both early rejects
 #pragma unroll
         for (int h = 0; h < 2; h++) {                     // pixels (0,1) then (2,3); selector byte 0x0c = constant zero
@@ -346,14 +350,23 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         }
         // per-wave list append, one ballot per pixel slot: position = n_mine + (survivors of this slot in lower lanes), which
         // v_mbcnt delivers with the base folded in; the survivor count is scalar (s_bcnt1).  Entry order inside the list is free.
-        const int e0 = (ry << 8) + (cb - c0);             // cb - c0 may be negative for the first dword; e0 + t is not
+        const int e0 = (rbase << 8) + e_lane;             // cb - c0 may be negative for the first dword; e0 + t is not
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            bool keep = (t & 1) ? (int)okw[t >> 1] < 0 : (okw[t >> 1] & 0x8000u) != 0;
-            if (HAS_MASK) { if (keep) keep = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
-            const unsigned long long bal = __ballot(keep);
-            const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, (unsigned)n_mine));
-            if (keep) my_list[pos] = (unsigned short)(e0 + t);
+            bool keep;
+            unsigned long long bal;
+            if (HAS_MASK || (t & 1)) {
+                keep = (t & 1) ? (int)okw[t >> 1] < 0 : (okw[t >> 1] & 0x8000u) != 0;      // sign of the pixel's 16-bit half
+                if (HAS_MASK) { if (keep) keep = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
+                bal = __ballot(keep);
+            } else {
+                // the even pixel's flag is the sign of the LOW half: one 16-bit compare straight into the lane mask (the compiler's own
+                // forms - and + compare, bit-field extract + compare, both for one predicate - cost four instructions per slot)
+                asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(bal) : "v"(okw[t >> 1]));
+                keep = __builtin_amdgcn_inverse_ballot_w64(bal);
+            }
+            const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (keep) (my_list + n_mine)[pos] = (unsigned short)(e0 + t);      // (scalar base + lane rank: no move of n_mine into a vector register)
             n_mine += __popcll(bal);
         }
     }
