@@ -241,78 +241,87 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     const int flush_at = L.list_cap - DET_LIST_STEP;      // wave-uniform; never exceeded when the list holds the worst case
     int n_pos = 0;                                        // wave-uniform: positives at the front of the list
     bool dense = false;                                   // wave-uniform: the positives overflowed, phase 3 scans this wave's rows densely
-    for (int rbase = wave * rows_per_step;; rbase += 4 * rows_per_step) {
-        const bool p1_done = rbase >= L.score_rows;
-        if (p1_done || n_mine > flush_at) {
-            // ---- phase 2: full 16-ring test + score, each wave on ITS OWN survivor list (no barrier after phase 1) ----
-            // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
-            // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
-#if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 2
-            if (tile_out) { if (p1_done) break; n_mine = 0; continue; }
-#endif
-            for (int i0 = n_pos; i0 < n_mine; i0 += 64) {
-                const int i = i0 + lane;
-                bool hit = false;
-                int e = 0;
-                if (i < n_mine) {
-                    e = my_list[i];
-                    const int ry = e >> 8, rx = e & 255;
-                    const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
-                    const int v = c[0], vt = v + threshold, v_t = v - threshold;
-                    // the 16 ring pixels as 8 packed pairs (pixel 2i in the low, 2i+1 in the high half of P[i]): every test below works
-                    // on two pixels per instruction (v_pk_sub_i16 / v_perm / v_sad_u16)
-                    unsigned P[8];
-                    P[0] = (unsigned)c[3 * S] | ((unsigned)c[3 * S + 1] << 16);
-                    P[1] = (unsigned)c[2 * S + 2] | ((unsigned)c[S + 3] << 16);
-                    P[2] = (unsigned)c[3] | ((unsigned)c[-S + 3] << 16);
-                    P[3] = (unsigned)c[-2 * S + 2] | ((unsigned)c[-3 * S + 1] << 16);
-                    P[4] = (unsigned)c[-3 * S] | ((unsigned)c[-3 * S - 1] << 16);
-                    P[5] = (unsigned)c[-2 * S - 2] | ((unsigned)c[-S - 3] << 16);
-                    P[6] = (unsigned)c[-3] | ((unsigned)c[S - 3] << 16);
-                    P[7] = (unsigned)c[2 * S - 2] | ((unsigned)c[3 * S - 1] << 16);
-                    // brighter / darker: sign bit of (vt - p) [p > vt] and of (p - v_t) [p < v_t] per 16-bit half; v_perm collects the sign
-                    // bytes of four pixels into one dword E_j, and the four E_j are merged with staggered shifts: pixel 4j + b ends up at
-                    // bit 8b + 7 - j.  The population count is taken from this word directly; the arc LUT is stored in the matching
-                    // bit order (build_lut_bits, ring_bit_of_pixel), so the rare lookup only squeezes the word to 16 bits.
-                    typedef short s2 __attribute__((ext_vector_type(2)));
-                    const s2 vt2 = __builtin_bit_cast(s2, (unsigned)vt * 0x10001u), v_t2 = __builtin_bit_cast(s2, ((unsigned)v_t & 0xFFFFu) * 0x10001u);
-                    unsigned bright = 0, dark = 0;
+    // ---- phase 2 (called when the list could not take another early-reject step, and once at the end): full 16-ring test + score,
+    // each wave on ITS OWN survivor list (no barrier after phase 1) ----
+    // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
+    // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
+    auto ring_pass = [&]() {
+        for (int i0 = n_pos; i0 < n_mine; i0 += 64) {
+            const int i = i0 + lane;
+            bool hit = false;
+            int e = 0;
+            if (i < n_mine) {
+                e = my_list[i];
+                const int ry = e >> 8, rx = e & 255;
+                const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
+                const int v = c[0], vt = v + threshold, v_t = v - threshold;
+                // the 16 ring pixels as 8 packed pairs (pixel 2i in the low, 2i+1 in the high half of P[i]): every test below works
+                // on two pixels per instruction (v_pk_sub_i16 / v_perm / v_sad_u16)
+                unsigned P[8];
+                P[0] = (unsigned)c[3 * S] | ((unsigned)c[3 * S + 1] << 16);
+                P[1] = (unsigned)c[2 * S + 2] | ((unsigned)c[S + 3] << 16);
+                P[2] = (unsigned)c[3] | ((unsigned)c[-S + 3] << 16);
+                P[3] = (unsigned)c[-2 * S + 2] | ((unsigned)c[-3 * S + 1] << 16);
+                P[4] = (unsigned)c[-3 * S] | ((unsigned)c[-3 * S - 1] << 16);
+                P[5] = (unsigned)c[-2 * S - 2] | ((unsigned)c[-S - 3] << 16);
+                P[6] = (unsigned)c[-3] | ((unsigned)c[S - 3] << 16);
+                P[7] = (unsigned)c[2 * S - 2] | ((unsigned)c[3 * S - 1] << 16);
+                // brighter / darker: sign bit of (vt - p) [p > vt] and of (p - v_t) [p < v_t] per 16-bit half; v_perm collects the sign
+                // bytes of four pixels into one dword E_j, and the four E_j are merged with staggered shifts: pixel 4j + b ends up at
+                // bit 8b + 7 - j.  The population count is taken from this word directly; the arc LUT is stored in the matching
+                // bit order (build_lut_bits, ring_bit_of_pixel), so the rare lookup only squeezes the word to 16 bits.
+                typedef short s2 __attribute__((ext_vector_type(2)));
+                const s2 vt2 = __builtin_bit_cast(s2, (unsigned)vt * 0x10001u), v_t2 = __builtin_bit_cast(s2, ((unsigned)v_t & 0xFFFFu) * 0x10001u);
+                unsigned bright = 0, dark = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const s2 p0 = __builtin_bit_cast(s2, P[2 * j]), p1 = __builtin_bit_cast(s2, P[2 * j + 1]);
-                        const unsigned eb = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, (s2)(vt2 - p1)), __builtin_bit_cast(unsigned, (s2)(vt2 - p0)), 0x07050301u);
-                        const unsigned ed = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, (s2)(p1 - v_t2)), __builtin_bit_cast(unsigned, (s2)(p0 - v_t2)), 0x07050301u);
-                        bright |= (eb >> j) & (0x80808080u >> j);
-                        dark |= (ed >> j) & (0x80808080u >> j);
-                    }
-                    // arc LUT (8 KB bit table, global): a divergent dword gather costs the vector-memory pipeline ~1 lane/clk, so masks
-                    // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
-                    // of them is ever looked up, usually none)
-                    unsigned lb = 0;
-                    if (__popc(bright) >= min_pop) { const unsigned ix = ring_word_to_index(bright); lb = lut_bits[ix >> 5] >> (ix & 31); }
-                    if (__popc(dark) >= min_pop) { const unsigned ix = ring_word_to_index(dark); lb |= lut_bits[ix >> 5] >> (ix & 31); }
-                    hit = (lb & 1u) != 0;
-                    if (hit) {
-                        const unsigned v2 = (unsigned)v * 0x10001u;
-                        unsigned sad = 0;
-#pragma unroll
-                        for (int k = 0; k < 8; k++) sad = __builtin_amdgcn_sad_u16(P[k], v2, sad);
-                        s_score[__umul24(ry, L.score_w) + rx] = (unsigned short)sad;
-                    }
+                for (int j = 0; j < 4; j++) {
+                    const s2 p0 = __builtin_bit_cast(s2, P[2 * j]), p1 = __builtin_bit_cast(s2, P[2 * j + 1]);
+                    const unsigned eb = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, (s2)(vt2 - p1)), __builtin_bit_cast(unsigned, (s2)(vt2 - p0)), 0x07050301u);
+                    const unsigned ed = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, (s2)(p1 - v_t2)), __builtin_bit_cast(unsigned, (s2)(p0 - v_t2)), 0x07050301u);
+                    bright |= (eb >> j) & (0x80808080u >> j);
+                    dark |= (ed >> j) & (0x80808080u >> j);
                 }
-                const unsigned long long bal = __ballot(hit);
-                if (hit && !dense) (my_list + n_pos)[__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
-                n_pos += __popcll(bal);
+                // arc LUT (8 KB bit table, global): a divergent dword gather costs the vector-memory pipeline ~1 lane/clk, so masks
+                // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
+                // of them is ever looked up, usually none)
+                unsigned lb = 0;
+                if (__popc(bright) >= min_pop) { const unsigned ix = ring_word_to_index(bright); lb = lut_bits[ix >> 5] >> (ix & 31); }
+                if (__popc(dark) >= min_pop) { const unsigned ix = ring_word_to_index(dark); lb |= lut_bits[ix >> 5] >> (ix & 31); }
+                hit = (lb & 1u) != 0;
+                if (hit) {
+                    const unsigned v2 = (unsigned)v * 0x10001u;
+                    unsigned sad = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) sad = __builtin_amdgcn_sad_u16(P[k], v2, sad);
+                    s_score[__umul24(ry, L.score_w) + rx] = (unsigned short)sad;
+                }
             }
-            if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
-            n_mine = n_pos;
-            if (p1_done) break;
+            const unsigned long long bal = __ballot(hit);
+            if (hit && !dense) (my_list + n_pos)[__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
+            n_pos += __popcll(bal);
         }
-        // a step whose rows all lie in the image's 20-pixel border (or below the band) has no pixel to test: 12 % of the steps at the
-        // EuRoC geometry, 30 % of the rows of the smallest level (wave-uniform: rbase and y0 live in SGPRs)
-        if (y0 - 1 + rbase + rows_per_step - 1 < JSORB_BORDER || y0 - 1 + rbase >= H - JSORB_BORDER) continue;
-        // (per step and lane: one address addition - the step's row offset is scalar, the lane's part loop-invariant - and two compares
-        // against the band's valid rows; a row past the region reads the LDS bytes behind the image rows and is masked off below)
+        if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
+        n_mine = n_pos;
+    };
+    // The wave's early-reject steps: rows rbase (+1) of the region, every 4th step of the workgroup.  Steps whose rows all lie in the
+    // image's 20-pixel border have no pixel to test (12 % of the steps at the EuRoC geometry, 30 % of the rows of the smallest level):
+    // the loop runs over the others only - a plain counted loop; written as one loop with the ring test inside and `continue` for the
+    // border steps, the compiler built a state machine of ~75 scalar instructions per step, as many as the vector ones.
+    const int step_rows = 4 * rows_per_step;
+    int rb_first = wave * rows_per_step;
+    {
+        const int rb_min = JSORB_BORDER - (y0 - 1) - (rows_per_step - 1);            // first rbase with a row at or below the border line
+        const int sh = two_rows ? 3 : 2;                                                 // step_rows is 8 or 4
+        if (rb_first < rb_min) rb_first += ((rb_min - rb_first + step_rows - 1) >> sh) << sh;
+    }
+    const int rb_end = min(L.score_rows, H - JSORB_BORDER - (y0 - 1));               // rbase < rb_end: the region and the image's interior
+#if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 2
+#define DET_RING_PASS() do { n_mine = 0; } while (0)
+#else
+#define DET_RING_PASS() ring_pass()
+#endif
+    for (int rbase = rb_first; rbase < rb_end; rbase += step_rows) {
+        if (n_mine > flush_at) DET_RING_PASS();
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
         const bool row_ok = ry >= ry_lo && ry <= ry_hi;
@@ -370,6 +379,8 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
             n_mine += __popcll(bal);
         }
     }
+    DET_RING_PASS();
+#undef DET_RING_PASS
 #undef PK
 
     __syncthreads();
