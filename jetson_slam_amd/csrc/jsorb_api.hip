@@ -246,6 +246,8 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         if (n_ty * 128 > 1024) n_ty = 1024 / 128;
         lv.n_ty = n_ty;
         lv.mini_tile = (lv.th - 1) / n_ty + 1;
+        lv.recip_nty = (65536 + n_ty - 1) / n_ty;
+        lv.recip_tw = (65536 + lv.tw - 1) / lv.tw;
         lv.log2_tw = 0;
         while ((1 << lv.log2_tw) < lv.tw) lv.log2_tw++;
         // this build's workgroup tables

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_blur(Geometry g, ImageSrc src, const ui
     // the level in the third: the first image byte cannot be requested earlier (see k_detect)
     asm volatile("" ::"s"(ctab), "s"(slab), "s"(blur_slab), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.detect_blocks));
     int b, blk;
-    if (!xcd_map(blockIdx.x, g.blur_blocks, n_images, b, blk)) return;
+    if (!xcd_map(g.blur_blocks, n_images, b, blk)) return;
     const unsigned wd = ctab_load(ctab, ctab_blur(g) + blk);
     const int lvl = (int)(wd & 15u), by = (int)((wd >> 4) & 0x3FFFu), bx = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
@@ -331,7 +331,7 @@ void blur_tile_dims(int *tw, int *th) { *tw = BLUR_TW; *th = BLUR_TH; }
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s)
 {
     if (g.blur_blocks == 0) return;
-    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(g.blur_blocks, n_images)), dim3(256), 0, s, g, src, slab, blur_slab, ctab, n_images);
+    hipLaunchKernelGGL(k_blur, xcd_grid(g.blur_blocks, n_images), dim3(256), 0, s, g, src, slab, blur_slab, ctab, n_images);
 }
 
 } // namespace jsorb

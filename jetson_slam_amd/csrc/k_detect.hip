@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
     asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
     int b, blk;
-    if (!xcd_map(blockIdx.x, g.detect_blocks, n_images, b, blk)) return;
+    if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
     // workgroup descriptor (level, tile row, tile group) from the host-built table behind the LUT: one scalar load instead of a
     // chain of dependent ones - the kernel is sensitive to the latency of this prologue (no vector work can start before it)
     const unsigned wd = ctab_load(lut_bits, CTAB_DETECT + blk);
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // one ds_max_u32 per positive on a per-TILE key (score << 18 | 127 - column priority << 11 | 2047 - row rank) yields the
     // tile winner directly; otherwise the key is per column and phase 4 replays the tree.
     const int SW = L.score_w;
-    const int n_ty = lv.n_ty, recip_nty = (65536 + n_ty - 1) / n_ty, recip_tw = (65536 + tw - 1) / tw;
+    const int n_ty = lv.n_ty, recip_nty = lv.recip_nty, recip_tw = lv.recip_tw;
     const bool ranked = lv.tree_rank_ok != 0;
     const unsigned char *s_rank = reinterpret_cast<const unsigned char *>(s_tree);      // rank[128], inv[128]
     auto nms_one = [&](int ry, int rx) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
-#define DETECT_LAUNCH(M, C) hipLaunchKernelGGL((k_detect<M, C>), dim3(xcd_grid(g.detect_blocks, n_images)), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
+#define DETECT_LAUNCH(M, C) hipLaunchKernelGGL((k_detect<M, C>), xcd_grid(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
     if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH(true, true); else DETECT_LAUNCH(true, false); }
     else            { if (g.lut_compass) DETECT_LAUNCH(false, true); else DETECT_LAUNCH(false, false); }
 #undef DETECT_LAUNCH

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
     const int lane = threadIdx.x;
     const int grp = lane / SGL, sl = lane % SGL;
     int b, blk;
-    if (!xcd_map(blockIdx.x, (g.T + SKPW - 1) / SKPW, n_pairs, b, blk)) return;
+    if (!xcd_map((g.T + SKPW - 1) / SKPW, n_pairs, b, blk)) return;
     const int Nl = uniform_i32(countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
     const int Nr = uniform_i32(countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
     if (blk * SKPW >= Nl) return;                     // whole wave idle
@@ -574,7 +574,7 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
                    float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_stereo, dim3(xcd_grid((g.T + SKPW - 1) / SKPW, n_pairs)), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
+    hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + SKPW - 1) / SKPW, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
                        outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs);
 }
 
