@@ -374,17 +374,9 @@ def main():
     shared_stream = torch.cuda.Stream(dev)
     for e in handles:
         e.set_stream(shared_stream.cuda_stream)
-        e.reset_kernel_timing()
         e.enable_kernel_timing(True)
-    for _ in range(args.profile_steps):
-        step()
-    fence()
-    kt = {}
+    kt = timed_steps(handles, step, fence, args.profile_steps)
     for e in handles:
-        for k, (ms, n) in e.kernel_times().items():
-            a = kt.setdefault(k, [0.0, 0])
-            a[0] += ms
-            a[1] += n
         e.enable_kernel_timing(False)
 
     # ---- north-star regime (i) at N > 1: every rank streams its own pairs from its own pinned host buffers at the same time (per-GPU PCIe
@@ -402,7 +394,7 @@ def main():
                     "sample": "all %d ranks at the same time, each: %s" % (world, hs["sample"])}
     if rank == 0:
         ab, Ppx, T = algo_bytes_per_pair(exl)
-        per_step_ms = {k: v[0] / max(1, args.profile_steps) for k, v in kt.items()}
+        per_step_ms = {k: v[2] for k, v in kt.items()}
         if args.profile_steps <= 0 or not any(v[1] for v in kt.values()):
             kt = {"k_detect": [1.0, 1]}                 # no profiling pass requested: the roofline block is a placeholder
             per_step_ms = {"k_detect": 0.0}
@@ -522,6 +514,32 @@ def valu_view(config, pairs_per_s, n_cus, clock_hz):
         return None
 
 
+def timed_steps(handles, step, fence, n_steps):
+    """Per-kernel hipEvent times of n_steps steps, ONE step at a time: {kernel: [median step's ms, its launches, that same ms]} - the median over
+    the steps, not their mean: with event pairs around every launch the host is the slower side, the GPU runs dry between steps and the
+    first kernels after an idle gap are sometimes timed at two or three times their duration (seen as k_pyramid or k_median 'dominating')."""
+    per = {}
+    for _ in range(max(0, n_steps)):
+        for e in handles:
+            e.reset_kernel_timing()
+        step()
+        fence()
+        acc = {}
+        for e in handles:
+            for k, (ms, n) in e.kernel_times().items():
+                x = acc.setdefault(k, [0.0, 0])
+                x[0] += ms
+                x[1] += n
+        for k, (ms, n) in acc.items():
+            per.setdefault(k, []).append((ms, n))
+    out = {}
+    for k, v in per.items():
+        v.sort()
+        ms, n = v[len(v) // 2]
+        out[k] = [ms, n, ms]
+    return out
+
+
 def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seconds=0.8, cache={}):
     """The other BASELINE configurations in the driver-run line: device-resident batches of P pairs through ONE handle pair, every unique pair
     checked against the oracle, per-kernel hipEvent pass for the dominant kernel's roofline fraction."""
@@ -574,18 +592,10 @@ def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seco
     one = torch.cuda.Stream(dev)
     for e in (a, b):
         e.set_stream(one.cuda_stream)
-        e.reset_kernel_timing()
         e.enable_kernel_timing(True)
-    for _ in range(3):
-        step()
-    fence()
-    kt = {}
-    for e in (a, b):
-        for k, (ms, cnt) in e.kernel_times().items():
-            x = kt.setdefault(k, [0.0, 0])
-            x[0] += ms; x[1] += cnt
+    kt = timed_steps((a, b), step, fence, 5)
     ab, Ppx, T = algo_bytes_per_pair(a)
-    per_step = {k: v[0] / 3.0 for k, v in kt.items() if v[1]}
+    per_step = {k: v[2] for k, v in kt.items() if v[1]}
     dom = max(per_step, key=per_step.get)
     avg_ms = kt[dom][0] / kt[dom][1]
     units = P if dom in ("k_stereo", "k_median") else P / 2.0
