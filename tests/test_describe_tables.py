@@ -1,0 +1,126 @@
+"""CPU checks of host-evaluable logic behind k_describe and k_stereo (no GPU):
+  * the constant tables of k_describe (jetson_slam_amd/csrc/describe_tables.h, compiled here with g++): FP8 codes of the pattern
+    against the OCP E4M3 definition, the LDS slot permutation, and the moment multipliers - the row-pair dot-product evaluation of
+    the intensity centroid, replayed in numpy exactly as the kernel's lanes do it, against the brute-force sums over the disc
+    (orb_FAST_orientation.cu:17-65) for every alignment of the staged patch;
+  * the exact run of scan-line buckets k_stereo computes per level (k_stereo.hip, `below` / `above` walk): replayed in float32 for
+    every row and a range of scales against the reference's row test floor(y - r) <= vL <= ceil(y + r) (orb_stereo_match.cu:119-140)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tables(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("dt") / "describe_tables_dump")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "jetson_slam_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "describe_tables_dump.cpp")])
+    return json.loads(subprocess.check_output([exe]))
+
+
+def _e4m3(byte):
+    """OCP FP8 E4M3 (bias 7, no infinities), the format v_cvt_pk_f32_fp8 decodes on gfx950"""
+    s, e, m = byte >> 7, (byte >> 3) & 15, byte & 7
+    v = (m / 8.0) * 2.0 ** -6 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7)
+    return -v if s else v
+
+
+def test_pattern_fp8_codes_decode_to_the_pattern_and_slots_are_a_permutation(tables):
+    q, slot, X, Y = tables["pattern_q"], tables["slot"], tables["x"], tables["y"]
+    assert sorted(slot) == list(range(256))
+    assert min(X + Y) >= -13 and max(X + Y) <= 13                     # E4M3 holds the integers up to 16 exactly
+    for b in range(256):
+        w = q[slot[b]]
+        got = [_e4m3((w >> (8 * k)) & 0xFF) for k in range(4)]
+        assert got == [X[2 * b], X[2 * b + 1], Y[2 * b], Y[2 * b + 1]], b
+    # lane sl reads four 16-byte chunks at dwords sl*16 + 4*((c + sl//4) % 4): the 16 lanes of a keypoint hit 16 different groups of 4 banks
+    for c in range(4):
+        groups = {((sl * 16 + 4 * ((c + sl // 4) % 4)) % 64) // 4 for sl in range(16)}
+        assert len(groups) == 16
+    # and the step-major order: chunk c of lane sl holds steps 4c .. 4c+3 (descriptor bits it*16 + sl)
+    for sl in range(16):
+        for it in range(16):
+            assert slot[it * 16 + sl] == sl * 16 + 4 * (((it >> 2) + (sl >> 2)) & 3) + (it & 3)
+
+
+def test_moment_multipliers_reproduce_the_disc_sums_for_every_alignment(tables):
+    umax = tables["umax"]
+    assert umax == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    mom = np.array(tables["moment"], dtype=np.uint64).reshape(8, 16, 2)
+    rng = np.random.default_rng(5)
+    for trial in range(24):
+        a = trial % 8                                                  # (x - 15) & 7: offset of the keypoint's column -15 inside the staged row
+        rows = rng.integers(0, 256, (31, 48), dtype=np.int64)          # staged rows: 48 bytes from the 8-byte aligned column
+        if trial >= 16:
+            rows[:] = 255                                              # saturated patch: the largest sums
+        # brute force (reference): m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]
+        m10 = m01 = 0
+        for v in range(-15, 16):
+            for u in range(-umax[abs(v)], umax[abs(v)] + 1):
+                px = int(rows[15 + v, a + 15 + u])
+                m10 += u * px
+                m01 += v * px
+        # the kernel's evaluation: lane v owns rows 15 + v and 15 - v; step d takes the dword of columns -15 + 4d .. -12 + 4d
+        # (bytes a + 4d .. a + 4d + 3 of the staged row: two aligned dwords + alignbyte) into dot products with the table's multipliers
+        g10 = g01 = 0
+        for lane in range(16):
+            p1 = p2 = n1 = n2 = s1 = s2 = 0
+            for d in range(8):
+                cu, inn = int(mom[d, lane, 0]), int(mom[d, lane, 1])
+                w1 = rows[15 + lane, a + 4 * d:a + 4 * d + 4]
+                w2 = rows[15 - lane, a + 4 * d:a + 4 * d + 4]
+                mu = [(cu >> (8 * j)) & 0xFF for j in range(4)]
+                mi = [(inn >> (8 * j)) & 0xFF for j in range(4)]
+                du1, du2 = int(np.dot(w1, mu)), int(np.dot(w2, mu))
+                if d < 4:
+                    n1 += du1; n2 += du2
+                else:
+                    p1 += du1; p2 += du2
+                s1 += int(np.dot(w1, mi)); s2 += int(np.dot(w2, mi))
+                assert max(p1, p2, n1, n2, s1, s2) < 2 ** 32            # u32 accumulators of v_dot4_u32_u8
+            g10 += (p1 - n1) + ((p2 - n2) if lane else 0)
+            g01 += lane * (s1 - s2)
+        assert (g10, g01) == (m10, m01), (trial, a)
+    # the widest read of a lane: dwords at bytes (a & 4) + 4d and + 4 more, shifted by a & 3 -> last byte a + 4*7 + 3 + (4 - ...) stays inside the 48-byte row
+    assert 7 + 4 * 7 + 3 < 48 and (7 & 4) + 4 * 8 + 3 < 48
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def test_scan_line_bucket_runs_equal_the_references_row_test():
+    """k_stereo.hip: lo = floor(vL - 2 - r), hi = ceil(vL + 2 + r); `below` = how many of lo .. lo+4 have ceil(y + r) < vL, `above` = how many
+    of hi .. hi-4 have floor(y - r) > vL; the run is [lo + below, hi - above].  Must equal {y : floor(y - r) <= vL <= ceil(y + r)} with every
+    sum rounded to float32 as on the device, for every row and scale (the monotonicity argument of DESIGN.md, checked by enumeration)."""
+    scales = []
+    for sf in (1.2, 1.1, 1.5, 2.0, 1.05, 1.25):
+        s = np.float32(1.0)
+        for lvl in range(12):
+            scales.append(s)
+            s = np.float32(s * np.float32(sf))
+    scales = sorted({float(x) for x in scales if x < 19.0})          # (the library rejects level scales of 19 and more)
+    ys = np.arange(-128, 8300, dtype=np.float32)
+    checked = 0
+    for sc in scales:
+        r = _f32(2.0) * _f32(sc)
+        lo_row = np.floor(ys - r)              # float32 arithmetic throughout (ys, r are float32)
+        hi_row = np.ceil(ys + r)
+        assert np.all(np.diff(lo_row) >= 0) and np.all(np.diff(hi_row) >= 0)      # non-decreasing in y
+        for vL in list(range(0, 64)) + list(range(470, 490)) + list(range(1000, 1100, 7)) + list(range(2040, 2060)) + list(range(4090, 4100)) + [8191]:
+            vLf = _f32(vL)
+            lo_f = np.floor(vLf - _f32(2.0) - r)
+            hi_f = np.ceil(vLf + _f32(2.0) + r)
+            below = sum(1 for k in range(5) if np.ceil((lo_f + _f32(k)) + r) < vLf)
+            above = sum(1 for k in range(5) if np.floor((hi_f - _f32(k)) - r) > vLf)
+            ylo, yhi = int(lo_f) + below, int(hi_f) - above
+            passing = ys[(lo_row <= vLf) & (vLf <= hi_row)].astype(np.int64)
+            assert passing.size > 0 and passing[0] == ylo and passing[-1] == yhi and passing.size == yhi - ylo + 1, (sc, vL, ylo, yhi, passing[:3], passing[-3:])
+            assert below < 5 and above < 5                             # the walk never runs out of its five candidates
+            checked += 1
+    assert checked > 5000

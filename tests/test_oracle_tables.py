@@ -32,8 +32,8 @@ def test_umax_table(po):
     # orb_gpu.cpp:161-182 for HALF_PATCH 15 (OpenCV's ORB umax)
     ex = po.OracleExtractor(height=64, width=64, n_levels=1, tile_h=8, tile_w=8)
     assert ex.umax().tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
-    # the product kernel hard-codes the same table as packed nibbles (k_describe.hip umax15)
-    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_describe.hip")).read()
+    # the product kernel hard-codes the same table as packed nibbles (describe_tables.h umax15)
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "describe_tables.h")).read()
     tab = int(re.search(r"tab = (0x[0-9A-Fa-f]+)ull", src).group(1), 16)
     assert [(tab >> (4 * v)) & 0xF for v in range(16)] == ex.umax().tolist()
 
