@@ -18,8 +18,8 @@ valu = {"_source": "profiles/%s_sq_counters.csv (_c3, _c5): rocprofv3 --pmc SQ_I
         "_units": "VALU wave-instructions per kernel launch; _pairs_per_launch images per extract-side launch and pairs per stereo-side launch"}
 for cfg, t in cfgs.items():
     h = json.load(open(os.path.join(O, t + "_hbm_traffic.json")))
-    traffic.setdefault("_note", h.get("_note", "") + "; k_pyramid's per-lane 16-byte tap-row loads overlap between neighbouring lanes and rows "
-                       "(whether the x2 correction applies to that pattern is uncalibrated)")
+    traffic.setdefault("_note", h.get("_note", "") + "; calibrated for gathers too (profiles/r03_fetch_calibration.txt: the L2 fetches whole 128-byte lines whatever part "
+                       "of them is asked for, one request per line tallied at 64 bytes), so the figure is 128 bytes x lines fetched for every kernel")
     traffic[cfg] = h[cfg]
     traffic["_raw_kb"][cfg] = h["_raw_kb"]
     sq = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(O, t + "_sq_counters.csv")))}
