@@ -37,6 +37,11 @@ namespace jsorb {
 #define DET_LIST_CAP 640
 #endif
 #define DET_LIST_STEP 256
+// waves per workgroup: they share the staged tile and take its region rows in turn
+#ifndef DET_NW
+#define DET_NW 4
+#endif
+#define DET_THREADS (64 * DET_NW)
 
 struct DetectLds {
     int img_stride;      // bytes per LDS image row (multiple of 16)
@@ -59,7 +64,7 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     // rejects - would cost 7.8 KB at tile 30 and hold the kernel at 7 workgroups per CU): when a wave's list could not take another
     // early-reject step (DET_LIST_STEP entries), the wave runs its ring test on what it has - only positives stay in the list - and
     // goes on; if even the positives do not fit, the wave falls back to a dense scan of its rows in phase 3.
-    const int full = 2 * ((d.score_rows + 7) / 8) * d.score_w;
+    const int full = 2 * ((d.score_rows + 2 * DET_NW - 1) / (2 * DET_NW)) * d.score_w;
     d.list_cap = full <= DET_LIST_CAP ? full : DET_LIST_CAP;
     size_t o = (size_t)d.img_stride * d.img_rows;
     o = (o + 15) & ~(size_t)15;
@@ -67,7 +72,7 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     o += (size_t)d.score_w * d.score_rows * 2;
     o = (o + 15) & ~(size_t)15;
     d.off_list = o;
-    o += (size_t)d.list_cap * 4 * 2;
+    o += (size_t)d.list_cap * DET_NW * 2;
     o = (o + 15) & ~(size_t)15;
     d.off_colkey = o;
     o += 128 * 4;
@@ -133,7 +138,7 @@ __device__ __forceinline__ unsigned ring_word_to_index(unsigned w)
 int detect_ring_bit_of_pixel(int k) { return ring_bit_of_pixel(k); }
 
 template <bool HAS_MASK, bool COMPASS>
-__global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
+__global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     constexpr int S = DET_S;
     const int xs = (xg0 - 4) & ~15;                       // 16-byte aligned (may be negative)
     constexpr int nq16 = S >> 4;                          // 10 units of 16 B per LDS row
-    constexpr int rpp = 256 / nq16;                       // 25 rows per pass (250 of the 256 threads)
+    constexpr int rpp = DET_THREADS / nq16;               // 25 rows per pass (250 of the 256 threads)
     {
         // a thread keeps its column and walks down the tile with a constant pointer stride: no per-item index arithmetic
         const int dx = tid % nq16, ly0 = tid / nq16;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     {
         const int nsc = (L.score_w * L.score_rows * 2 + 15) >> 4;
         uint4 *z = reinterpret_cast<uint4 *>(s_score);
-        for (int i = tid; i < nsc; i += 256) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < nsc; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
         if (tid < 128) s_colkey[tid] = 0;
         if (lv.tree_rank_ok && tid < 64) reinterpret_cast<unsigned *>(s_tree)[tid] = lut_bits[ctab_tree(g) + 64 * lvl + tid];      // column priorities
     }
@@ -310,11 +315,12 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     // image's 20-pixel border have no pixel to test (12 % of the steps at the EuRoC geometry, 30 % of the rows of the smallest level):
     // the loop runs over the others only - a plain counted loop; written as one loop with the ring test inside and `continue` for the
     // border steps, the compiler built a state machine of ~75 scalar instructions per step, as many as the vector ones.
-    const int step_rows = 4 * rows_per_step;
+    const int step_rows = DET_NW * rows_per_step;
     int rb_first = wave * rows_per_step;
     {
         const int rb_min = JSORB_BORDER - (y0 - 1) - (rows_per_step - 1);            // first rbase with a row at or below the border line
-        const int sh = two_rows ? 3 : 2;                                                 // step_rows is 8 or 4
+        static_assert(DET_NW == 4 || DET_NW == 8, "step_rows must be a power of two");
+        const int sh = (DET_NW == 8 ? 3 : 2) + (two_rows ? 1 : 0);                        // log2(step_rows)
         if (rb_first < rb_min) rb_first += ((rb_min - rb_first + step_rows - 1) >> sh) << sh;
     }
     const int rb_end = min(L.score_rows, H - JSORB_BORDER - (y0 - 1));               // rbase < rb_end: the region and the image's interior
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
     } else {
         // the wave's positives did not fit its list (a tile of almost nothing but corners): every pixel of the rows this wave owned
         // in phase 1 is looked at; s_score holds 0 wherever there is no corner
-        for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += 4 * rows_per_step)
+        for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += DET_NW * rows_per_step)
             for (int ry = rbase; ry < rbase + rows_per_step && ry < L.score_rows; ry++)
                 for (int rx = lane; rx < SW; rx += 64) nms_one(ry, rx);
     }
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
         const int sub = tw <= 8 ? 8 : tw <= 16 ? 16 : tw <= 32 ? 32 : 64;
         const int tpw = 64 / sub;                         // tiles per wave-step
         const int j = lane & (sub - 1);                   // column inside the tile
-        for (int tile0 = wave * tpw; tile0 < lv.k_tiles; tile0 += 4 * tpw) {
+        for (int tile0 = wave * tpw; tile0 < lv.k_tiles; tile0 += DET_NW * tpw) {
             const int tile = tile0 + lane / sub;
             const int col = tile * tw + j;
             const bool in_tile = j < tw && tile < lv.k_tiles;
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256) void k_detect(Geometry g, ImageSrc src, const 
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
-#define DETECT_LAUNCH(M, C) hipLaunchKernelGGL((k_detect<M, C>), xcd_grid(g.detect_blocks, n_images), dim3(256), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
+#define DETECT_LAUNCH(M, C) hipLaunchKernelGGL((k_detect<M, C>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
     if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH(true, true); else DETECT_LAUNCH(true, false); }
     else            { if (g.lut_compass) DETECT_LAUNCH(false, true); else DETECT_LAUNCH(false, false); }
 #undef DETECT_LAUNCH
