@@ -409,7 +409,7 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     const unsigned char *s_rank = reinterpret_cast<const unsigned char *>(s_tree);      // rank[128], inv[128]
     auto nms_one = [&](int ry, int rx) {
         if (ry < 1 || ry > th || rx < 1 || rx > ktw) return;          // halo entries only serve as neighbours
-        const unsigned short *q = s_score + ry * SW + rx;
+        const unsigned short *q = s_score + __umul24(ry, SW) + rx;     // (24-bit multiplies: v_mul_lo_u32 issues at a quarter of the rate)
         const int s = q[0];
         const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
                            s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];
@@ -417,13 +417,13 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
         int dy = ry - 1, trow = 0;                                       // tile row inside the band and row inside that tile (R <= 4)
         if (R > 1) {
             trow = (dy >= th1) + (dy >= 2 * th1) + (dy >= 3 * th1);
-            dy -= trow * th1;
+            dy -= __umul24(trow, th1);
         }
-        const int kk = (dy * recip_nty) >> 16, ty = dy - kk * n_ty;      // dy / n_ty, exact for dy < 8192 (n_ty <= 8)
+        const int kk = (int)(__umul24(dy, recip_nty) >> 16), ty = dy - (int)__umul24(kk, n_ty);      // dy / n_ty, exact for dy < 255 (n_ty <= 8; dy * recip < 2^24)
         const unsigned rank = (unsigned)(ty * 256 + kk);                 // lexicographic (ty, k); k < mini_tile <= 128
         if (ranked) {
-            const int tile = ((rx - 1) * recip_tw) >> 16, cit = rx - 1 - tile * tw;      // (rx-1) / tw, exact for rx-1 < 512
-            atomicMax(&s_colkey[trow * lv.k_tiles + tile], ((unsigned)s << 18) | ((127u - s_rank[cit]) << 11) | (2047u - rank));
+            const int tile = (int)(__umul24(rx - 1, recip_tw) >> 16), cit = rx - 1 - (int)__umul24(tile, tw);      // (rx-1) / tw, exact for rx-1 < 128 (product < 2^24)
+            atomicMax(&s_colkey[__umul24(trow, lv.k_tiles) + tile], ((unsigned)s << 18) | ((127u - s_rank[cit]) << 11) | (2047u - rank));
         } else {
             atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
         }
