@@ -12,9 +12,12 @@
 //   :563-578  sort by L1 distance, median, thDist = 1.5f*1.4f*median, remove everything >= thDist
 // The reference crosses host<->device >= 12 times per frame here, with cudaMalloc/cudaFree and cublasCreate/Destroy
 // inside the frame loop and M*1331 floats written to HBM only to be summed; this version never leaves the device.
-// Candidate pruning uses the tile-row start table produced by k_compact (keypoints of one tile row are contiguous
-// and ordered), then applies the reference's exact row / octave / u tests; candidate order (ascending iR) only matters
-// for ties, which the (distance << 20 | iR) min-key reproduces.
+// Candidates come from the scan-line buckets k_compact sorts the right keypoints into (one bucket per level and level-0 row: the
+// reference's vRowIndices, :119-140, with every keypoint listed once); the run of buckets that covers the left keypoint's row is
+// computed exactly per level, the reference's disparity-window test follows per candidate.  The tile-row start tables of k_compact
+// (keypoints of one tile row are contiguous and ordered) remain as the fallback for geometries whose buckets do not fit k_compact's
+// LDS (JSORB_STEREO_EPI=0 forces it).  Candidate order (ascending iR in the reference) only matters for ties, which the
+// (distance << 20 | iR) min-key reproduces.
 #include "jsorb_launch.h"
 
 namespace jsorb {
