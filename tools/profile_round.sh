@@ -7,8 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# PROFILE_ARGS="--config c3 --pairs 64" profiles another configuration (no bench line then); tag it e.g. r03c3
-if [ -z "$PROFILE_ARGS" ]; then python $ROOT/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; fi
+# PROFILE_ARGS="--config c3 --pairs 64" profiles another configuration (no bench line then); tag it e.g. r03c3.  PROFILE_NO_BENCH=1 skips the
+# bench line for the default configuration too (profiles first, then tools/profile_merge.py, then `python bench.py` reads the fresh counters).
+if [ -z "$PROFILE_ARGS" ] && [ -z "$PROFILE_NO_BENCH" ]; then python $ROOT/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; fi
 B="python $ROOT/bench.py --steps 10 --warmup 2 --min-time 0 --no-cpu-baseline --no-extras --profile-steps 0 --single-stream $PROFILE_ARGS"   # one stream: per-kernel durations are not inflated by left/right overlap
 rm -rf $O/${TAG}_trace $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o t -- $B > $O/${TAG}_trace.log 2>&1
