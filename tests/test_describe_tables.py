@@ -124,3 +124,61 @@ def test_scan_line_bucket_runs_equal_the_references_row_test():
             assert below < 5 and above < 5                             # the walk never runs out of its five candidates
             checked += 1
     assert checked > 5000
+
+
+def test_bucket_candidate_search_finds_exactly_the_references_candidates():
+    """The candidate search of k_compact + k_stereo restated in numpy on the ORACLE's keypoints of a stereo pair: every right keypoint listed
+    once under (level, level-0 row), the run of buckets per level from the walk above, the disparity-window test per candidate - against the
+    reference's definition (row table over [floor(y - r), ceil(y + r)], octave within +-1, uR in [uL - maxD, uL]; orb_stereo_match.cu:119-184)
+    evaluated by brute force, and against the oracle's own count of candidate pairs."""
+    from jetson_slam_amd.synth import synth_stereo_pair
+    from oracle import pyoracle as po
+    H, W, L, tile, th, fx, bf = 376, 620, 8, 25, 60, 718.856, 386.1448
+    l, r = synth_stereo_pair(77, H, W)
+    mk = lambda: po.OracleExtractor(height=H, width=W, n_levels=L, tile_h=tile, tile_w=tile, th_fast_max=th)
+    ol, orr = mk(), mk()
+    ol.extract(l); orr.extract(r)
+    mb = bf / fx
+    _, _, ost = po.stereo_match(ol, orr, mb, bf)
+    kl, kr = ol.keypoints().reshape(6, -1), orr.keypoints().reshape(6, -1)
+    scales = ol.scales()
+    xl, yl, lvl_l = kl[0], kl[1], kl[4]
+    xr, yr, lvl_r = kr[0], kr[1], kr[4]
+    assert len(xl) > 300 and len(xr) > 300 and yr.max() < H and xr.max() < 32768
+    minD, maxD = np.float32(0.0), np.float32(np.float32(bf) / np.float32(mb))      # Frame.cpp: maxD = mbf / mb
+    # --- buckets as k_compact builds them: (level, row) -> list of right keypoint indices
+    buckets = {}
+    for j in range(len(xr)):
+        buckets.setdefault((int(lvl_r[j]), min(int(yr[j]), H - 1)), []).append(j)
+    total_ref = total_bkt = 0
+    for i in range(len(xl)):
+        uL, vL, lv = np.float32(xl[i]), np.float32(yl[i]), int(lvl_l[i])
+        vLi = int(vL)
+        minU, maxU = uL - maxD, uL - minD
+        # reference definition, brute force over all right keypoints
+        ref = set()
+        for j in range(len(xr)):
+            rr = np.float32(2.0) * scales[lvl_r[j]]
+            kpY = np.float32(yr[j])
+            if int(np.floor(kpY - rr)) <= vLi <= int(np.ceil(kpY + rr)) and abs(int(lvl_r[j]) - lv) <= 1:
+                uR = np.float32(xr[j])
+                if minU <= uR <= maxU and not maxU < 0:
+                    ref.add(j)
+        # the kernel's search
+        got = set()
+        if not maxU < 0:
+            for lr in (lv - 1, lv, lv + 1):
+                if lr < 0 or lr >= L:
+                    continue
+                rr = np.float32(2.0) * scales[lr]
+                vLf = np.float32(vLi)
+                lo_f, hi_f = np.floor(vLf - np.float32(2.0) - rr), np.ceil(vLf + np.float32(2.0) + rr)
+                below = sum(1 for k in range(5) if np.ceil((lo_f + np.float32(k)) + rr) < vLf)
+                above = sum(1 for k in range(5) if np.floor((hi_f - np.float32(k)) - rr) > vLf)
+                for y in range(max(int(lo_f) + below, 0), min(int(hi_f) - above, H - 1) + 1):
+                    for j in buckets.get((lr, y), ()):
+                        if minU <= np.float32(xr[j]) <= maxU:
+                            got.add(j)
+        assert got == ref, (i, sorted(got ^ ref)[:5])
+        total_ref += len(ref); total_bkt += len(got)
+    assert total_bkt == total_ref == ost["n_candidate_pairs"]
