@@ -481,7 +481,10 @@ __device__ __noinline__ void median_big(MedianShared &sm, const Geometry &g, con
 // Median cut of one stereo pair per workgroup (orb_stereo_match.cu:560-580: sort, median = dist[size/2], thDist = 1.5*1.4*median, matches
 // with dist >= thDist lose uRight / depth) + the per-pair statistics.  Pairs with at most 256 * MED_R left keypoints keep their L1
 // distances in registers over the three passes.
-#define MED_R 32
+// Two builds: 32 distances per thread (pairs of up to 8 192 left keypoints: every shipped configuration but the KAIST-shaped one) and 64
+// (up to 16 384: the KAIST-shaped pairs hold 12.8 k, and the three-pass re-reading form took 71 us per launch there); the launch picks by the
+// handle's keypoint capacity, the kernel still falls back to median_big() when a pair exceeds its build.
+template <int MED_R>
 __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restrict__ countsL, float *__restrict__ u_right,
                                                 float *__restrict__ depth, const int *__restrict__ best_l1,
                                                 const unsigned *__restrict__ aux, int *__restrict__ stats, DeliverStereo dl)
@@ -584,7 +587,8 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
                    int *stats, int n_pairs, hipStream_t s, DeliverStereo dl)
 {
-    hipLaunchKernelGGL(k_median, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, aux, stats, dl);
+    if (g.T <= 256 * 32) hipLaunchKernelGGL(k_median<32>, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, aux, stats, dl);
+    else hipLaunchKernelGGL(k_median<64>, dim3(n_pairs), dim3(256), 0, s, g, countsL, u_right, depth, best_l1, aux, stats, dl);
 }
 
 } // namespace jsorb
