@@ -1,5 +1,5 @@
 // describe_tables.h - the constant tables of k_describe.hip as plain constexpr C++17 (no HIP in here): the kernel file includes it,
-// and tests/test_describe_tables.py compiles tests/cpp/describe_tables_dump.cpp with g++ to check the tables on the CPU (FP8 codes
+// and tests/test_round3_host_logic.py compiles tests/cpp/describe_tables_dump.cpp with g++ to check the tables on the CPU (FP8 codes
 // against the E4M3 definition, the LDS slot permutation, the moment multipliers against a brute-force sum over the disc).
 #pragma once
 #include "orb_pattern.inc"

@@ -1,4 +1,4 @@
-// Prints the constant tables of k_describe (jetson_slam_amd/csrc/describe_tables.h) as JSON - compiled with g++ by tests/test_describe_tables.py
+// Prints the constant tables of k_describe (jetson_slam_amd/csrc/describe_tables.h) as JSON - compiled with g++ by tests/test_round3_host_logic.py
 #include <cstdio>
 
 #include "describe_tables.h"

@@ -182,3 +182,61 @@ def test_bucket_candidate_search_finds_exactly_the_references_candidates():
         assert got == ref, (i, sorted(got ^ ref)[:5])
         total_ref += len(ref); total_bkt += len(got)
     assert total_bkt == total_ref == ost["n_candidate_pairs"]
+
+
+def test_detect_counted_loop_visits_exactly_the_non_border_steps():
+    """k_detect.hip: the early-reject steps of wave w are rbase = w*rps, + NW*rps, ... < score_rows, minus those whose rows all lie in the
+    image's 20-pixel border (round-3 first half: `continue` inside the loop).  The counted loop of the second half starts at
+    rb_first = first step >= BORDER - (y0-1) - (rps-1) on that lattice and ends below rb_end = min(score_rows, H - BORDER - (y0-1)).
+    Same set of steps for every band position, image height, region height, wave and row pairing."""
+    BORDER, NW = 20, 4
+    checked = 0
+    for rps in (1, 2):
+        step_rows = NW * rps
+        sh = {4: 2, 8: 3}[step_rows]
+        for H in (60, 97, 240, 376, 480):
+            for score_rows in (10, 17, 32, 62, 122):
+                for y0 in range(0, H, 7):
+                    for wave in range(NW):
+                        old = [rb for rb in range(wave * rps, score_rows, step_rows)
+                               if not (y0 - 1 + rb + rps - 1 < BORDER or y0 - 1 + rb >= H - BORDER)]
+                        rb_first = wave * rps
+                        rb_min = BORDER - (y0 - 1) - (rps - 1)
+                        if rb_first < rb_min:
+                            rb_first += ((rb_min - rb_first + step_rows - 1) >> sh) << sh
+                        rb_end = min(score_rows, H - BORDER - (y0 - 1))
+                        new = list(range(rb_first, rb_end, step_rows))
+                        assert new == old, (rps, H, score_rows, y0, wave)
+                        checked += 1
+    assert checked > 3000
+
+
+def test_three_dimensional_grid_enumerates_the_same_image_block_pairs():
+    """jsorb_device.h xcd_grid / xcd_map: grid (8, nb, ceil(n/8)) with b = z*8 + x, blk = y for batches of 8 and more images (workgroups of one
+    image on one XCD when dispatched x-fastest), (nb, n) below; the linear form (nb > 65535) divides.  Every (image, block) pair exactly once,
+    and the x-fastest linear order of the 3-D grid is the linear form's order."""
+    def grid3(nb, n):
+        return (8, nb, (n + 7) // 8) if n >= 8 else (nb, n, 1)
+
+    def map3(x, y, z, nb, n):
+        return (z * 8 + x, y) if n >= 8 else (y, x)
+
+    def map_linear(lin, nb, n):
+        if n >= 8:
+            q = lin >> 3
+            return ((q // nb) * 8 + (lin & 7), q - (q // nb) * nb)
+        return (lin // nb, lin - (lin // nb) * nb)
+
+    for nb in (1, 3, 57, 220):
+        for n in (1, 2, 7, 8, 9, 16, 33):
+            gx, gy, gz = grid3(nb, n)
+            seen, lin = [], 0
+            for z in range(gz):
+                for y in range(gy):
+                    for x in range(gx):
+                        b, blk = map3(x, y, z, nb, n)
+                        assert (b, blk) == map_linear(lin, nb, n)
+                        lin += 1
+                        if b < n:
+                            seen.append((b, blk))
+            assert sorted(seen) == [(b, k) for b in range(n) for k in range(nb)]
