@@ -127,3 +127,41 @@ def test_zero_byte_flags_have_no_false_negative():
     y = (g ^ (g << np.uint32(1))) & np.uint32(0xFEFEFEFE)
     z = ~y & (y - np.uint32(0x01010101)) & np.uint32(0x80808080)
     assert (z != 0).mean() < 0.01
+
+
+def _lane_window_max_offset(s, W):
+    """Largest byte offset a lane of k_pyramid reads inside its slot: right tap of its last column relative to the dword-aligned start
+    (the kernel's f32 expressions: xl = floor(fl(s * w)))."""
+    w = np.arange(0, W, 4)
+    x0 = np.floor(np.float32(s) * w.astype(np.float32)).astype(np.int64)
+    x3 = np.floor(np.float32(s) * np.minimum(w + 3, W - 1).astype(np.float32)).astype(np.int64)
+    return int((x3 + 1 - (x0 & ~3)).max())
+
+
+def test_loads_per_row_cover_the_lane_window():
+    """pyramid_loads_per_row (k_pyramid.hip): the 16-byte loads of a lane must cover byte offset floor(3 s) + 5 inclusive in the worst case (the round-3
+    budget of floor(3 s) + 5 BYTES was one short: scaleFactor 1.25 with 7 levels, 1.3 with 6, 1.4 with 5 sampled past their slot).  The product now
+    enumerates the level's lanes; this restates that enumeration and pins the counter-example of the round-3 review (s = 1.25^6, w = 44)."""
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jetson_slam_amd", "csrc", "k_pyramid.hip")).read()
+    assert "max_off / 16 + 1" in src and "x3 + 1 - (x0 & ~3)" in src
+    s = np.float32(1.0)
+    for _ in range(6):
+        s = np.float32(s * np.float32(1.25))
+    s = np.float32(1.0) / (np.float32(1.0) / s)
+    xl = [int(np.floor(s * np.float32(44 + t))) for t in range(4)]
+    assert xl == [167, 171, 175, 179] and xl[3] + 1 - (xl[0] & ~3) == 16           # a second 16-byte load is needed
+    assert _lane_window_max_offset(s, 197) // 16 + 1 == 2
+    rng = np.random.default_rng(5)
+    for sc in list(rng.uniform(1.0, 18.0, 300)) + [1.2 ** k for k in range(1, 12)] + [1.25 ** 6, 1.3 ** 5, 1.4 ** 4, 3.05 ** 2, 2.0, 4.0, 8.0]:
+        for W in (37, 209, 1241, 4096):
+            off = _lane_window_max_offset(sc, W)
+            assert off <= int(np.float32(3.0) * np.float32(sc)) + 5 + 1            # +1: f32 rounding of s * w may cross an integer
+            assert off // 16 + 1 <= 4 or sc > 18
+    # every level of the three BASELINE pyramids still takes ONE load per lane and row (no change of the benchmarked kernels)
+    for W0 in (752, 1241, 1280):
+        sc = np.float32(1.0)
+        for lvl in range(1, 8):
+            sc = np.float32(sc * np.float32(1.2))
+            s_k = np.float32(1.0) / (np.float32(1.0) / sc)
+            Wl = int(np.round(W0 / sc))
+            assert _lane_window_max_offset(s_k, Wl) <= 15, (W0, lvl)
