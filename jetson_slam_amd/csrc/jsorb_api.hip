@@ -934,6 +934,10 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
                 const int m0 = j & 1, m4 = (j >> 4) & 1, m8 = (j >> 8) & 1, m12 = (j >> 12) & 1;
                 if (!((m0 | m8) & (m4 | m12))) g.lut_compass = 0;
             }
+        // The 6-bit early rejects accept a superset of the exact ones; that is only allowed where the early rejects are no part of the result, i.e.
+        // where the arc LUT alone decides (lut_compass: every accepted mask passes the compass test, so the exact ring test of phase 2 is the whole
+        // semantics).  With an arc LUT that accepts masks the reference's early rejects throw away (N_MIN < 9) the exact form stays.
+        g.det_swar_t4 = g.lut_compass ? detect_swar6_threshold(g.threshold) : 0;
         {   // reference bit order -> the order k_detect indexes the table with
             std::vector<uint32_t> ref(bits.begin(), bits.begin() + 2048);
             permute_lut_bits(ref, bits.data());

@@ -21,6 +21,7 @@ size_t detect_lds_bytes(const Geometry &g);
 
 size_t pyramid_lds_bytes(const Geometry &g);
 int pyramid_loads_per_row(float s, int W); // 16-byte loads per lane and level-0 row in k_pyramid for a level of scale s and width W (exact, by enumeration)
+int detect_swar6_threshold(int threshold);   // k_detect: threshold of the 6-bit early rejects if they provably accept a superset of the exact ones (exhaustive check), else 0
 void fill_pyramid_layout(Geometry &g);     // rows per k_pyramid tile (pyr_th), sparse windows, workgroup table offsets (host side, once per handle)
 void launch_upload_level0(const uint8_t *host_pinned, uint8_t *dst, size_t bytes, hipStream_t s);      // bytes: a multiple of 16
 void launch_copy_level0(const uint8_t *src, size_t image_stride, int step, uint8_t *slab, size_t slab_bytes, int pitch, int W, int H, int n_images, hipStream_t s);

@@ -24,6 +24,7 @@
 //   * phase 4: the reference's horizontal tree replayed literally on <= 128 column slots in LDS.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "jsorb_launch.h"
 
@@ -111,6 +112,9 @@ void fill_detect_layout(Geometry &g)
         dblk += ((lv.nth + R - 1) / R) * lv.groups_per_row;
         const DetectLds d = detect_lds_layout(R * lv.th, lv.tw, lv.k_tiles, lv.tree_rank_ok);
         lv.det_score_w = d.score_w; lv.det_score_rows = d.score_rows; lv.det_img_rows = d.img_rows; lv.det_list_cap = d.list_cap;
+        // a list that holds the worst case (every pixel of the wave's rows survives) never needs the early ring test or the dense fallback
+        const int full = 2 * ((d.score_rows + 2 * DET_NW - 1) / (2 * DET_NW)) * d.score_w;
+        lv.det_flush_at = d.list_cap >= full ? 0x7fffffff : d.list_cap - DET_LIST_STEP;
         lv.det_off_score = (int)d.off_score; lv.det_off_list = (int)d.off_list; lv.det_off_colkey = (int)d.off_colkey; lv.det_off_tree = (int)d.off_tree;
     }
     g.detect_blocks = dblk;
@@ -126,6 +130,27 @@ size_t detect_lds_bytes(const Geometry &g)
     return m;
 }
 
+// Early rejects on 6-bit pixels (k_detect phase 1, SWAR form): with q(x) = x >> 2 and t4 = (th + 1) >> 2,
+//   p > v + th  =>  q(p) - q(v) >= t4        and        p < v - th  =>  q(v) - q(p) >= t4
+// (floor((v + th + 1) / 4) >= floor(v / 4) + floor((th + 1) / 4)), so the 6-bit tests accept a SUPERSET of what the exact tests accept, and the
+// compass / near-pair combinations of phase 1 are monotone in their flags.  In 8-bit fields the sums q(p) + (128 - t4 - q(v)) and
+// (128 - t4 + q(v)) - q(p) stay inside [1, 191]: no carry or borrow between the four pixels of a dword, bit 7 of a field IS the flag.
+// Returns t4 if the property holds for every (v, p) - checked exhaustively, not assumed - and the test still rejects something (t4 >= 2), else 0.
+int detect_swar6_threshold(int threshold)
+{
+    const int thc = std::min(threshold, 256), t4 = (thc + 1) >> 2;
+    if (t4 < 2 || getenv("JSORB_DETECT_EXACT_REJECT")) return 0;
+    const int cb = 128 - t4;
+    for (int v = 0; v < 256; v++)
+        for (int p = 0; p < 256; p++) {
+            const int y = (p >> 2) + (cb - (v >> 2)), z = (cb + (v >> 2)) - (p >> 2);
+            if (y < 0 || y > 255 || z < 0 || z > 255 || cb - (v >> 2) < 0 || cb + (v >> 2) > 255) return 0;      // a field would carry into its neighbour
+            if (p > v + threshold && !(y & 0x80)) return 0;
+            if (p < v - threshold && !(z & 0x80)) return 0;
+        }
+    return t4;
+}
+
 // Bit order of the ring masks inside k_detect's phase 2 (see there): the 32-bit word has ring pixel 4j + b at bit 8b + 7 - j; squeezed
 // to 16 bits for the arc LUT, pixel 4j + b sits at bit 4b + 3 - j.  build_lut_bits() on the host stores the LUT in this order.
 __host__ __device__ __forceinline__ int ring_bit_of_pixel(int k) { return 4 * (k & 3) + 3 - (k >> 2); }
@@ -137,7 +162,26 @@ __device__ __forceinline__ unsigned ring_word_to_index(unsigned w)
 }
 int detect_ring_bit_of_pixel(int k) { return ring_bit_of_pixel(k); }
 
-template <bool HAS_MASK, bool COMPASS>
+// -DDET_TIMING (tools/micro/detect_phases.py builds that variant): every wave adds the shader clocks it spent in each phase to global counters
+#ifdef DET_TIMING
+#define DET_TSLOTS 2048
+__device__ unsigned long long g_det_timing[DET_TSLOTS][16];      // spread over many lines: atomics of 10^5 waves on ONE address serialise and distort what they measure
+#define DET_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DET_TACC(k, a, b) do { det_t[k] = (b) - (a); } while (0)
+extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
+{
+    static unsigned long long h[DET_TSLOTS][16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_det_timing), sizeof(h)) != hipSuccess) return -1;
+    for (int k = 0; k < 16; k++) { out16[k] = 0; for (int i = 0; i < DET_TSLOTS; i++) out16[k] += h[i][k]; }
+    memset(h, 0, sizeof(h));
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_det_timing), h, sizeof(h)) == hipSuccess ? 0 : -1;
+}
+#else
+#define DET_T(var) do { } while (0)
+#define DET_TACC(k, a, b) do { } while (0)
+#endif
+
+template <bool HAS_MASK, bool COMPASS, bool SWAR>
 __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
 {
@@ -148,6 +192,10 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
     int b, blk;
     if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
+#ifdef DET_TIMING
+    unsigned long long det_t[9] = {};
+#endif
+    DET_T(t_start);
     // workgroup descriptor (level, tile row, tile group) from the host-built table behind the LUT: one scalar load instead of a
     // chain of dependent ones - the kernel is sensitive to the latency of this prologue (no vector work can start before it)
     const unsigned wd = ctab_load(lut_bits, CTAB_DETECT + blk);
@@ -202,7 +250,10 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
         if (tid < 128) s_colkey[tid] = 0;
         if (lv.tree_rank_ok && tid < 64) reinterpret_cast<unsigned *>(s_tree)[tid] = lut_bits[ctab_tree(g) + 64 * lvl + tid];      // column priorities
     }
+    DET_T(t_staged);
     __syncthreads();
+    DET_T(t_p1);
+    DET_TACC(0, 0ull, 1ull); DET_TACC(1, t_start, t_staged); DET_TACC(2, t_staged, t_p1);
 #if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 1
     if (tile_out) return;
 #endif
@@ -228,11 +279,12 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     // that lie inside [c_lo, c_hi) (interior columns of this tile group)
     const int qq = q < nq ? q0 + q : q0;                  // keep LDS addresses in range for idle lanes
     const int cb = 4 * qq;
-    // cm[h]: sign-bit positions (bit 15 = pixel 2h, bit 31 = pixel 2h+1) of the lane's pixels that lie inside [c_lo, c_hi)
-    unsigned cm[2] = {0u, 0u};
+    // cm[h]: sign-bit positions (bit 15 = pixel 2h, bit 31 = pixel 2h+1) of the lane's pixels that lie inside [c_lo, c_hi);
+    // cmF: the same set as bit 7 of byte t (the flag word of the SWAR form)
+    unsigned cm[2] = {0u, 0u}, cmF = 0u;
 #pragma unroll
     for (int t = 0; t < 4; t++)
-        if (q < nq && (unsigned)(cb + t - c_lo) < c_span) cm[t >> 1] |= (t & 1) ? 0x80000000u : 0x8000u;
+        if (q < nq && (unsigned)(cb + t - c_lo) < c_span) { cm[t >> 1] |= (t & 1) ? 0x80000000u : 0x8000u; cmF |= 0x80u << (8 * t); }
     // two pixels per instruction in the 16-bit halves of a dword (v_pk_*_i16); every test ends as the sign bit of a packed
     // difference.  th >= 256 behaves like 256 (every pixel is "near").
     typedef short s2 __attribute__((ext_vector_type(2)));
@@ -246,14 +298,18 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     const int ry_lo = max(0, JSORB_BORDER - (y0 - 1)), ry_hi = min(L.score_rows - 1, H - JSORB_BORDER - 1 - (y0 - 1));      // region rows inside the image's interior (wave-uniform)
     const int e_lane = (sub << 8) + (cb - c0);                                           // list entry of the lane's first pixel in row `sub`
     const int min_pop = g.lut_min_pop;
-    const int flush_at = L.list_cap - DET_LIST_STEP;      // wave-uniform; never exceeded when the list holds the worst case
+    const int flush_at = lv.det_flush_at;                 // wave-uniform; INT_MAX when the list holds the worst case (no early ring test, no dense fallback)
     int n_pos = 0;                                        // wave-uniform: positives at the front of the list
     bool dense = false;                                   // wave-uniform: the positives overflowed, phase 3 scans this wave's rows densely
     // ---- phase 2 (called when the list could not take another early-reject step, and once at the end): full 16-ring test + score,
     // each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
     // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
+#ifdef DET_TIMING
+    unsigned long long t_ring = 0;
+#endif
     auto ring_pass = [&]() {
+        DET_T(t_r0);
         for (int i0 = n_pos; i0 < n_mine; i0 += 64) {
             const int i = i0 + lane;
             bool hit = false;
@@ -310,6 +366,9 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
         }
         if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
         n_mine = n_pos;
+#ifdef DET_TIMING
+        t_ring += __builtin_amdgcn_s_memtime() - t_r0;
+#endif
     };
     // The wave's early-reject steps: rows rbase (+1) of the region, every 4th step of the workgroup.  Steps whose rows all lie in the
     // image's 20-pixel border have no pixel to test (12 % of the steps at the EuRoC geometry, 30 % of the rows of the smallest level):
@@ -329,14 +388,41 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
 #else
 #define DET_RING_PASS() ring_pass()
 #endif
+    int e_cur = (rb_first << 8) + e_lane;                  // list entry of the lane's first pixel in the current step
     for (int rbase = rb_first; rbase < rb_end; rbase += step_rows) {
         if (n_mine > flush_at) DET_RING_PASS();
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
-        const bool row_ok = ry >= ry_lo && ry <= ry_hi;
         const unsigned *rowp = reinterpret_cast<const unsigned *>(lane_img + (rbase + 3) * S);
         const unsigned Dm = rowp[-1], D0 = rowp[0], Dp = rowp[1];
         const unsigned Du = rowp[-3 * (S >> 2)], Dd = rowp[3 * (S >> 2)];
+        const int e0 = e_cur;                             // (rbase << 8) + e_lane: cb - c0 may be negative for the first dword; e0 + t is not
+        e_cur += step_rows << 8;
+        unsigned FA, FB;                                  // SWAR: flags of pixels 1, 3 in bits 15, 31 of FA and of pixels 0, 2 in bits 15, 31 of FB; exact form: okw[0], okw[1]
+        if constexpr (SWAR) {
+            // ---- 6-bit form: FOUR pixels per instruction, plain 32-bit and / add / sub (which issue at twice the rate of the packed
+            // 16-bit and permute instructions, profiles/r04_valu_rate.txt).  Host-proven superset of the exact test (detect_swar6_threshold);
+            // phase 2 recomputes both ring masks exactly, so a few extra survivors cost time, never a result. ----
+            constexpr unsigned M6 = 0x3f3f3f3fu;
+            const unsigned cbk = (unsigned)(128 - g.det_swar_t4) * 0x01010101u;
+            const unsigned c6 = (D0 >> 2) & M6, u6 = (Du >> 2) & M6, d6 = (Dd >> 2) & M6;
+            const unsigned r6 = __builtin_amdgcn_alignbit(Dp, D0, 26) & M6;      // pixels x + 3: bytes 3 of D0 and 0..2 of Dp, each >> 2
+            const unsigned l6 = __builtin_amdgcn_alignbit(D0, Dm, 10) & M6;      // pixels x - 3: bytes 1..3 of Dm and 0 of D0, each >> 2
+            const unsigned kb = cbk - c6, kd = cbk + c6;
+            const unsigned y4 = r6 + kb, y12 = l6 + kb, y0 = d6 + kb, y8 = u6 + kb;      // bit 7 of a byte: that pixel is brighter than v + th (or nearly)
+            const unsigned z4 = kd - r6, z12 = kd - l6, z0 = kd - d6, z8 = kd - u6;      // darker than v - th (or nearly)
+            static_assert(COMPASS || !SWAR, "the 6-bit form is a superset filter: only where the arc LUT alone decides (lut_compass)");
+            unsigned F = ((y4 | y12) & (y0 | y8)) | ((z4 | z12) & (z0 | z8));
+            // rows outside the image's interior: only the first / last step of a band next to the border has one
+            unsigned rowmask = cmF;
+            if (rbase < ry_lo || rbase + rows_per_step - 1 > ry_hi) {      // a real (scalar) branch: the asm keeps the compiler from turning it into selects on every step
+                rowmask = (ry >= ry_lo && ry <= ry_hi) ? cmF : 0u;
+                asm volatile("" : "+v"(rowmask));
+            }
+            F &= rowmask;
+            FA = F; FB = F << 8;
+        } else {
+        const bool row_ok = ry >= ry_lo && ry <= ry_hi;
         unsigned okw[2];                                  // sign bits (15 / 31): pixel 2h / 2h+1 survives both early rejects
 #pragma unroll
         for (int h = 0; h < 2; h++) {                     // pixels (0,1) then (2,3); selector byte 0x0c = constant zero
@@ -366,33 +452,46 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
             }
             okw[h] = ok & (row_ok ? cm[h] : 0u);
         }
+        FA = okw[0]; FB = okw[1];
+        }
         // per-wave list append, one ballot per pixel slot: position = n_mine + (survivors of this slot in lower lanes), which
         // v_mbcnt delivers with the base folded in; the survivor count is scalar (s_bcnt1).  Entry order inside the list is free.
-        const int e0 = (rbase << 8) + e_lane;             // cb - c0 may be negative for the first dword; e0 + t is not
+        // The flag of slot t is the sign of a 16-bit half: SWAR form - pixel 0 / 2 in FB's low / high half, 1 / 3 in FA's;
+        // exact form - pixel 0 / 1 in FA's, 2 / 3 in FB's.
 #pragma unroll
         for (int t = 0; t < 4; t++) {
+            const unsigned fw = SWAR ? ((t & 1) ? FA : FB) : ((t >> 1) ? FB : FA);
+            const bool high = SWAR ? (t >> 1) != 0 : (t & 1) != 0;
             bool keep;
             unsigned long long bal;
-            if (HAS_MASK || (t & 1)) {
-                keep = (t & 1) ? (int)okw[t >> 1] < 0 : (okw[t >> 1] & 0x8000u) != 0;      // sign of the pixel's 16-bit half
+            if (HAS_MASK || high) {
+                keep = high ? (int)fw < 0 : (fw & 0x8000u) != 0;      // sign of the pixel's 16-bit half
                 if (HAS_MASK) { if (keep) keep = mask[(size_t)y * lv.pitch + xs + cb + t] != 0; }
                 bal = __ballot(keep);
             } else {
-                // the even pixel's flag is the sign of the LOW half: one 16-bit compare straight into the lane mask (the compiler's own
+                // the flag is the sign of the LOW half: one 16-bit compare straight into the lane mask (the compiler's own
                 // forms - and + compare, bit-field extract + compare, both for one predicate - cost four instructions per slot)
-                asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(bal) : "v"(okw[t >> 1]));
+                asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(bal) : "v"(fw));
                 keep = __builtin_amdgcn_inverse_ballot_w64(bal);
             }
             const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (keep) (my_list + n_mine)[pos] = (unsigned short)(e0 + t);      // (scalar base + lane rank: no move of n_mine into a vector register)
+            // (entry = e0 + t as a 32-bit addition: the 16-bit one the compiler picks for the truncated value issues at half the rate)
+            unsigned ent = (unsigned)e0;
+            if (t) asm("v_add_u32_e32 %0, %1, %2" : "=v"(ent) : "n"(t), "v"(e0));
+            if (keep) (my_list + n_mine)[pos] = (unsigned short)ent;           // (scalar base + lane rank: no move of n_mine into a vector register)
             n_mine += __popcll(bal);
         }
     }
     DET_RING_PASS();
 #undef DET_RING_PASS
 #undef PK
-
+    DET_T(t_p2);
+#ifdef DET_TIMING
+    DET_TACC(3, t_p1 + t_ring, t_p2); DET_TACC(4, 0ull, t_ring);
+#endif
     __syncthreads();
+    DET_T(t_p3);
+    DET_TACC(5, t_p2, t_p3);
 #if defined(DET_KNOCKOUT) && (DET_KNOCKOUT == 2 || DET_KNOCKOUT == 3)
     if (tile_out) return;
 #endif
@@ -440,7 +539,10 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
             for (int ry = rbase; ry < rbase + rows_per_step && ry < L.score_rows; ry++)
                 for (int rx = lane; rx < SW; rx += 64) nms_one(ry, rx);
     }
+    DET_T(t_p3e);
     __syncthreads();
+    DET_T(t_p4);
+    DET_TACC(6, t_p3, t_p3e); DET_TACC(7, t_p3e, t_p4);
 #if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 4
     if (tile_out) return;
 #endif
@@ -464,6 +566,14 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
             tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] =
                 ((unsigned long long)(unsigned)sc << 32) | ((unsigned)(yy & 0xFFFF) << 16) | (unsigned)(xx & 0xFFFF);
         }
+        DET_T(t_end);
+        DET_TACC(8, t_p4, t_end);
+#ifdef DET_TIMING
+        if (lane == 0) {
+            unsigned long long *slot = g_det_timing[(blockIdx.x + 8 * blockIdx.y + 977 * blockIdx.z + 131 * wave) & (DET_TSLOTS - 1)];
+            for (int k = 0; k < 9; k++) atomicAdd(slot + k, det_t[k]);
+        }
+#endif
         return;
     }
 
@@ -547,9 +657,11 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
-#define DETECT_LAUNCH(M, C) hipLaunchKernelGGL((k_detect<M, C>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
-    if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH(true, true); else DETECT_LAUNCH(true, false); }
-    else            { if (g.lut_compass) DETECT_LAUNCH(false, true); else DETECT_LAUNCH(false, false); }
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
+#define DETECT_LAUNCH2(M) do { if (g.det_swar_t4 > 0) DETECT_LAUNCH(M, true, true); else DETECT_LAUNCH(M, true, false); } while (0)
+    if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH2(true); else DETECT_LAUNCH(true, false, false); }
+    else            { if (g.lut_compass) DETECT_LAUNCH2(false); else DETECT_LAUNCH(false, false, false); }
+#undef DETECT_LAUNCH2
 #undef DETECT_LAUNCH
 }
 

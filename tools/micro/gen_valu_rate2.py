@@ -45,8 +45,7 @@ OPS = [
     ("v_mbcnt_lo_u32_b32", "v_mbcnt_lo_u32_b32 v{d}, s70, v{b}"),
     ("v_cmp_gt_i16 (vcc)", "v_cmp_gt_i16 vcc, v{a}, v{b}"),
     ("v_cmp_gt_u32 (sgpr pair)", "v_cmp_gt_u32 s[{sp}:{sp1}], v{a}, v{b}"),
-    ("v_cndmask_b32", "v_cndmask_b32 v{d}, v{a}, v{b}, vcc"),
-    ("v_min_u32", "v_min_u32 v{d}, v{a}, v{b}"),
+        ("v_min_u32", "v_min_u32 v{d}, v{a}, v{b}"),
     ("v_max3_u32", "v_max3_u32 v{d}, v{a}, v{b}, v{c}"),
     ("v_mul_lo_u32", "v_mul_lo_u32 v{d}, v{a}, v{b}"),
     ("v_mul_u32_u24", "v_mul_u32_u24 v{d}, v{a}, v{b}"),
@@ -55,6 +54,55 @@ OPS = [
     ("v_mov_b32 dpp row_shr:1", "v_mov_b32_dpp v{d}, v{a} row_shr:1 row_mask:0xf bank_mask:0xf"),
     ("v_readlane_b32", "v_readlane_b32 s{sp}, v{a}, 5"),
     ("v_rcp_f32", "v_rcp_f32 v{d}, v{a}"),
+    ("v_sub_u32", "v_sub_u32 v{d}, v{a}, v{b}"),
+    ("v_xor_b32", "v_xor_b32 v{d}, v{a}, v{b}"),
+    ("v_not_b32", "v_not_b32 v{d}, v{a}"),
+    ("v_lshrrev_b32", "v_lshrrev_b32 v{d}, 1, v{a}"),
+    ("v_ashrrev_i32", "v_ashrrev_i32 v{d}, 7, v{a}"),
+    ("v_mul_f32", "v_mul_f32 v{d}, v{a}, v{b}"),
+    ("v_sub_f32", "v_sub_f32 v{d}, v{a}, v{b}"),
+    ("v_fmac_f32", "v_fmac_f32 v{d}, v{a}, v{b}"),
+    ("v_max_f32", "v_max_f32 v{d}, v{a}, v{b}"),
+    ("v_max_u32", "v_max_u32 v{d}, v{a}, v{b}"),
+    ("v_max_i32", "v_max_i32 v{d}, v{a}, v{b}"),
+    ("v_min_f32", "v_min_f32 v{d}, v{a}, v{b}"),
+    ("v_bitop3_b32", "v_bitop3_b32 v{d}, v{a}, v{b}, v{c} bitop3:0xe0"),
+    ("v_bfi_b32", "v_bfi_b32 v{d}, v{a}, v{b}, v{c}"),
+    ("v_lshl_add_u32", "v_lshl_add_u32 v{d}, v{a}, 1, v{b}"),
+    ("v_add_lshl_u32", "v_add_lshl_u32 v{d}, v{a}, v{b}, 1"),
+    ("v_xad_u32", "v_xad_u32 v{d}, v{a}, v{b}, v{c}"),
+    ("v_mad_i32_i24", "v_mad_i32_i24 v{d}, v{a}, v{b}, v{c}"),
+    ("v_add_co_u32 (vcc)", "v_add_co_u32 v{d}, vcc, v{a}, v{b}"),
+    ("v_pk_mov_b32", "v_pk_mov_b32 v[{e}:{e1}], v[{a2}:{a21}], v[{b2}:{b21}] op_sel:[0,1]"),
+    ("v_pk_mul_f32", "v_pk_mul_f32 v[{e}:{e1}], v[{a2}:{a21}], v[{b2}:{b21}]"),
+    ("v_pk_min_u16", "v_pk_min_u16 v{d}, v{a}, v{b}"),
+    ("v_pk_sub_u16 clamp", "v_pk_sub_u16 v{d}, v{a}, v{b} clamp"),
+    ("v_pk_lshrrev_b16", "v_pk_lshrrev_b16 v{d}, 1, v{a} op_sel_hi:[0,1]"),
+    ("v_cvt_u32_f32", "v_cvt_u32_f32 v{d}, v{a}"),
+    ("v_cvt_f32_u32", "v_cvt_f32_u32 v{d}, v{a}"),
+    ("v_cvt_f32_i32", "v_cvt_f32_i32 v{d}, v{a}"),
+    ("v_rndne_f32", "v_rndne_f32 v{d}, v{a}"),
+    ("v_floor_f32", "v_floor_f32 v{d}, v{a}"),
+    ("v_med3_i32", "v_med3_i32 v{d}, v{a}, v{b}, v{c}"),
+    ("v_add_u16", "v_add_u16 v{d}, v{a}, v{b}"),
+    ("v_add_u32 sdwa BYTE_1", "v_add_u32_sdwa v{d}, v{a}, v{b} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"),
+    ("v_mov_b32 sdwa BYTE_2", "v_mov_b32_sdwa v{d}, v{a} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2"),
+    ("v_add_u32 dpp row_shr:1", "v_add_u32_dpp v{d}, v{a}, v{b} row_shr:1 row_mask:0xf bank_mask:0xf"),
+    ("v_mov_b32 dpp wave_shr:1", "v_mov_b32_dpp v{d}, v{a} wave_shr:1 row_mask:0xf bank_mask:0xf"),
+    ("v_mov_b32 dpp quad_perm", "v_mov_b32_dpp v{d}, v{a} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"),
+    ("v_add_u32 (sgpr operand)", "v_add_u32 v{d}, s70, v{b}"),
+    ("v_and_b32 (literal)", "v_and_b32 v{d}, 0x7f7f7f7f, v{b}"),
+    ("v_cndmask_b32 e32 (vcc set before the loop)", "v_cndmask_b32 v{d}, v{a}, v{b}, vcc"),
+    ("v_cndmask_b32 e64 (sgpr pair)", "v_cndmask_b32 v{d}, v{a}, v{b}, s[70:71]"),
+    ("v_cmp_gt_i32 e32 (vcc)", "v_cmp_gt_i32 vcc, v{a}, v{b}"),
+    ("v_cmp_lt_i32 sdwa sext BYTE_0 (vcc)", "v_cmp_lt_i32_sdwa vcc, sext(v{a}), v{b} src0_sel:BYTE_0 src1_sel:DWORD"),
+    ("v_accvgpr_write_b32", "v_accvgpr_write_b32 a{d}, v{a}"),
+    ("v_accvgpr_read_b32", "v_accvgpr_read_b32 v{d}, a{d}"),
+    ("ds_bpermute_b32 (LDS pipe)", "ds_bpermute_b32 v{d}, v32, v{a}"),
+    ("ds_write_b16 (LDS only)", "ds_write_b16 v32, v{a}"),
+    ("ds_read_u8 (LDS only)", "ds_read_u8 v{d}, v32"),
+    ("s_bcnt1_i32_b64 (SALU only)", "s_bcnt1_i32_b64 s{sp}, s[70:71]"),
+    ("s_and_saveexec_b64 + restore (2 SALU)", "s_and_saveexec_b64 s[{sp}:{sp1}], s[70:71]\\n s_mov_b64 exec, s[{sp}:{sp1}]"),
     ("s_add_u32 (SALU only)", "s_add_u32 s{sp}, s{sp}, 3"),
     ("s_and_b64 (SALU only)", "s_and_b64 s[{sp}:{sp1}], s[{sp}:{sp1}], s[70:71]"),
     ("ds_read_b32 (LDS only)", "ds_read_b32 v{d}, v32"),
@@ -117,7 +165,7 @@ def main():
     out = []
     out.append("// GENERATED by tools/micro/gen_valu_rate2.py - do not edit.  See that file for what is measured.")
     out.append("#include <hip/hip_runtime.h>\n#include <cstdio>\n#include <cstdlib>\n#include <vector>\n#include <algorithm>\n")
-    clob = ", ".join('"v%d"' % i for i in range(40)) + ", " + ", ".join('"s%d"' % i for i in range(50, 76)) + ', "vcc", "scc", "memory"'
+    clob = ", ".join('"v%d"' % i for i in range(40)) + ", " + ", ".join('"s%d"' % i for i in range(50, 76)) + ', ' + ", ".join('"a%d"' % i for i in range(16)) + ', "vcc", "scc", "memory"'
     for i, (name, lines) in enumerate(kernels):
         asm = "\\n\"\n        \"".join(lines)
         out.append("""
@@ -129,7 +177,7 @@ __global__ __launch_bounds__(1024) void k%d(unsigned long long *out, int iters)
     unsigned long long t0, t1, r0, r1;
     asm volatile(
         "v_mbcnt_lo_u32_b32 v32, -1, 0\\n v_mbcnt_hi_u32_b32 v32, -1, v32\\n v_lshlrev_b32 v32, 2, v32\\n v_lshlrev_b32 v33, 2, v32\\n"
-        "s_mov_b64 s[70:71], -1\\n"
+        "s_mov_b64 s[70:71], -1\\n s_mov_b64 vcc, -1\\n"
         "v_mov_b32 v0, v32\\n v_mov_b32 v1, v32\\n v_mov_b32 v2, v32\\n v_mov_b32 v3, v32\\n v_mov_b32 v4, v32\\n v_mov_b32 v5, v32\\n v_mov_b32 v6, v32\\n v_mov_b32 v7, v32\\n"
         "v_mov_b32 v8, v32\\n v_mov_b32 v9, v32\\n v_mov_b32 v10, v32\\n v_mov_b32 v11, v32\\n v_mov_b32 v12, v32\\n v_mov_b32 v13, v32\\n v_mov_b32 v14, v32\\n v_mov_b32 v15, v32\\n"
         "v_mov_b32 v16, 1.0\\n v_mov_b32 v17, 0.5\\n v_mov_b32 v18, 1.0\\n v_mov_b32 v19, 0.5\\n v_mov_b32 v20, v32\\n v_mov_b32 v21, 2.0\\n v_mov_b32 v22, v32\\n v_mov_b32 v23, 1.0\\n"
@@ -184,7 +232,7 @@ int main(int argc, char **argv)
             for (int i = 0; i < nw; i++) { clk[i] = (double)h[2 * i]; mhz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 100.0 : 0.0; }
             std::sort(clk.begin(), clk.end()); std::sort(mhz.begin(), mhz.end());
             const double ninstr = (double)iters * k.n;
-            printf(" | %5.2f %5.0f %5.2f", clk[nw / 2] * w / ninstr / 1.0, mhz[nw / 2], ms * 1e-3 * 2.4e9 / (ninstr * w));
+            printf(" | %5.2f %5.0f %5.2f", clk[nw / 2] / (ninstr * w), mhz[nw / 2], ms * 1e-3 * 2.4e9 / (ninstr * w));
         }
         printf("\n"); fflush(stdout);
     }
