@@ -258,15 +258,9 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         dblk += lv.nth * lv.groups_per_row;
         lv.row_tab_off = rtab;
         rtab += lv.nth + 1;
-        const int rw = lv.W - 2 * JSORB_BORDER, rh = lv.H - 2 * JSORB_BORDER;
-        int btw, bth;
-        blur_tile_dims(&btw, &bth);
-        lv.blur_bx = rw > 0 ? (rw + btw - 1) / btw : 0;
-        lv.blur_by = rh > 0 ? (rh + bth - 1) / bth : 0;
-        if (lv.blur_bx == 0 || lv.blur_by == 0) { lv.blur_bx = 1; lv.blur_by = 0; }
-        lv.blur_blk0 = bblk;
-        bblk += lv.blur_bx * lv.blur_by;
     }
+    fill_blur_layout(g);                 // k_blur: strips of 8 columns x bands of rows, 256 items per workgroup
+    bblk = g.blur_blocks;
     (void)pblk;
     g.T = tiles;
     if (tiles >= (1 << 20)) { err = "too many tiles"; return JSORB_ERR_INVALID; }
@@ -948,16 +942,13 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
             uint8_t *tr = reinterpret_cast<uint8_t *>(&bits[ctab_tree(g) + 64 * i]);
             (void)build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128);      // tree_rank_ok was decided before the LDS layout (JSORB_FORCE_TREE_REPLAY: test hook)
         }
-        int btw, bth;
-        blur_tile_dims(&btw, &bth);
         for (int i = 0; i < g.L; i++) {
             const LevelDesc &lv = g.lv[i];
             for (int r = 0; r < (lv.nth + lv.det_R - 1) / lv.det_R; r++)          // r: group of det_R tile rows
                 for (int gr = 0; gr < lv.groups_per_row; gr++)
                     bits[CTAB_DETECT + lv.detect_blk0 + r * lv.groups_per_row + gr] = (uint32_t)i | ((uint32_t)r << 4) | ((uint32_t)gr << 18);
-            for (int by = 0; by < lv.blur_by; by++)
-                for (int bx = 0; bx < lv.blur_bx; bx++)
-                    bits[ctab_blur(g) + lv.blur_blk0 + by * lv.blur_bx + bx] = (uint32_t)i | ((uint32_t)by << 4) | ((uint32_t)bx << 18);
+            for (int wbk = 0; wbk < blur_level_blocks(lv); wbk++)
+                bits[ctab_blur(g) + lv.blur_blk0 + wbk] = (uint32_t)i | ((uint32_t)wbk << 4);      // level | workgroup of the level << 4
             if (i >= 1)
                 for (int by = 0; by < (lv.H + lv.pyr_th - 1) / lv.pyr_th; by++)
                     for (int bx = 0; bx < lv.pyr_bx; bx++)

@@ -33,7 +33,8 @@ void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, 
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s, int *counts_host = nullptr);
-void blur_tile_dims(int *tw, int *th);     // k_blur's workgroup tile (host-side launch table)
+void fill_blur_layout(Geometry &g);        // k_blur: strips x bands per level, workgroups per level (host side, once per handle)
+int blur_level_blocks(const LevelDesc &lv);
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s);
 void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *blur_slab,
                      const unsigned long long *kp, const int *counts, float *angles, uint8_t *desc, int32_t *out_kp,

@@ -18,7 +18,8 @@ U = Fraction(1, 2 ** 24)
 def _kernel_constants():
     src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur.hip")).read()
     delta = float(re.search(r"#define BLUR_BAND ([0-9.e+-]+)f", src).group(1))
-    assert delta == 2.0 ** -8 and "(f2){49152.0f, 49152.0f}" in src              # the band IS the ulp of the magic number
+    assert delta == 2.0 ** -8 and "const float magic = 49152.0f;" in src         # the band IS the ulp of the magic number
+    assert src.index("// horizontal stage") < src.index("// vertical stage")    # stage order of the kernel (round 4): horizontal sums first, vertical sum of those
     body = src[src.index("__constant__ float c_sep_v[4]"):]
     v = [float(t) for t in re.findall(r"([0-9.]+)f", body[:body.index(";")])]
     hb = body[body.index("c_sep_h[4]"):]
@@ -40,10 +41,10 @@ def test_delta_covers_the_rigorous_error_bound():
     sum_w = sum(sum(r) for r in wq)
     # chain of 49 FMAs: every term passes through at most 49 roundings
     bound_c = _gamma(49) * 255 * sum_w
-    # separable: 7-FMA vertical stage on values <= 255 * sum(gv), then 7-FMA horizontal stage on its results
-    vmax = 255 * sum(gv)
-    bound_v = _gamma(7) * vmax
-    bound_a = _gamma(7) * sum(gh) * (vmax + bound_v) + sum(gh) * bound_v
+    # separable: 7-FMA horizontal stage on values <= 255 * sum(gh), then 7-FMA vertical stage on its results
+    hmax = 255 * sum(gh)
+    bound_h = _gamma(7) * hmax
+    bound_a = _gamma(7) * sum(gv) * (hmax + bound_h) + sum(gv) * bound_h
     model = 255 * sum(abs(gv[j] * gh[k] - wq[j][k]) for j in range(7) for k in range(7))
     total = bound_c + bound_a + model                                     # (A + 49152 rounded down is floor(256 A) / 256 exactly: no further error)
     assert float(total) < 1.0e-3, float(total)
@@ -69,12 +70,12 @@ def test_certificate_decides_correctly_on_adversarial_windows():
         for j in range(7):
             for k in range(7):                                            # f32 fma via f64 (exact product, one extra rounding far below the margins)
                 acc = (np.float64(w[j, k]) * P[:, j, k] + acc.astype(np.float64)).astype(np.float32)
-        V = np.zeros((P.shape[0], 7), np.float32)
-        for j in range(7):
-            V = (np.float64(gv[j]) * P[:, j, :] + V.astype(np.float64)).astype(np.float32)
+        Hs = np.zeros((P.shape[0], 7), np.float32)                         # horizontal sums of the 7 window rows (left to right)
+        for k in range(7):
+            Hs = (np.float64(gh[k]) * P[:, :, k] + Hs.astype(np.float64)).astype(np.float32)
         A = np.zeros(P.shape[0], np.float32)
-        for k in (0, 1, 2, 3, 4, 5, 6):
-            A = (np.float64(gh[k]) * V[:, k] + A.astype(np.float64)).astype(np.float32)
+        for j in (0, 1, 2, 3, 4, 5, 6):                                    # vertical sum of those, oldest row first
+            A = (np.float64(gv[j]) * Hs[:, j] + A.astype(np.float64)).astype(np.float32)
         assert np.abs(A.astype(np.float64) - acc.astype(np.float64)).max() < 0.3 * delta
         q = np.floor(A.astype(np.float64) * 256.0).astype(np.int64)       # mantissa of A + 49152 rounded down
         frac, ipart = q & 0xFF, q >> 8
