@@ -155,6 +155,12 @@ int jsorb_copy_stereo(const jsorb_extractor *left, int image, float *u_right, fl
 /* Inspection (tests): the L1 window distance of the accepted sub-pixel refinement per left keypoint, -1 = none - the values the median
  * cut of orb_stereo_match.cu:560-580 sorts (vDistIdx[].first), N_left int32. */
 int jsorb_copy_stereo_l1(const jsorb_extractor *left, int image, int32_t *host_dst);
+/* Inspection (tests): keep the intermediate results of the matcher the reference holds on the host between its two kernels -
+ * per left keypoint 13 int32 = { best right index of K12's arg-min (-1: no candidate closer than th_high), its Hamming distance (th_high then),
+ * the 11 L1 window sums of K13 + cublasSgemv (-1 where no window search ran) } - orb_stereo_match.cu:241-256, 294-470.  Off by default
+ * (B x T x 52 bytes of device memory); while on, a speculative single-frame match is never adopted. */
+int jsorb_set_stereo_diagnostics(jsorb_extractor *left, int on);
+int jsorb_copy_stereo_diagnostics(const jsorb_extractor *left, int image, int32_t *host_dst /* 13 * N_left */);
 /* Multi-GPU batch mode: write (N_left, N_right, N_matched) of every pair of the last batch, 3 int32 per pair, to a DEVICE
  * buffer (enqueued on left's stream) - the payload of the one collective of this path, an all-gather of per-pair counts. */
 int jsorb_gather_counts_async(jsorb_extractor *left, jsorb_extractor *right, int32_t *dev_dst);

@@ -168,6 +168,7 @@ struct jsorb_extractor {
     int speculate = 0;                 // opt-in: jsorb_set_speculative_stereo(l, 1) (the C++ shim does it when it sees Frame's call shape) or JSORB_SPECULATE=1
     int speculate_env = -1;            // JSORB_SPECULATE, when set, wins over the call (0: never, 1: always)
     float *sp_u = nullptr, *sp_d = nullptr, *h_sp_u = nullptr, *h_sp_d = nullptr;   // twin output buffers (left handle), swapped in on adoption
+    int *st_diag = nullptr;            // jsorb_set_stereo_diagnostics: 13 int per left keypoint and image (B x T x 13), written by k_stereo when allocated
     const int *l1_view = nullptr;      // L1 distances of the last match: st_l1, or sp_l1 after an adopted speculative match (jsorb_copy_stereo_l1)
     int *sp_stats = nullptr, *h_sp_stats = nullptr, *sp_l1 = nullptr;   // sp_l1 / sp_aux: scratch of the speculative match (one pair)
     unsigned *sp_aux = nullptr;
@@ -1481,7 +1482,8 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
         TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, srcL, l->slab + (size_t)f * l->g.slab_bytes, srcR, r->slab + (size_t)f * r->g.slab_bytes,
                                               l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_stride,
-                                              l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st));
+                                              l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st,
+                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr));
         TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
                                               l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, l->h_stats + f * 8}));
         HIPCHK(l, hipGetLastError());
@@ -1548,6 +1550,29 @@ int jsorb_copy_stereo_l1(const jsorb_extractor *l, int image, int32_t *dst)
     return hipMemcpy(dst, l->l1_view + (size_t)image * l->g.T, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
 }
 
+int jsorb_set_stereo_diagnostics(jsorb_extractor *l, int on)
+{
+    if (!l) return JSORB_ERR_INVALID;
+    HIPCHK(l, hipSetDevice(l->device));
+    if (on && !l->st_diag) {
+        const size_t n = (size_t)l->B * l->g.T * JSORB_STEREO_DIAG_INTS * sizeof(int);
+        HIPCHK(l, hipMalloc(&l->st_diag, n));
+        HIPCHK(l, hipMemset(l->st_diag, 0xFF, n));
+    } else if (!on && l->st_diag) {
+        HIPCHK(l, hipDeviceSynchronize());
+        HIPCHK(l, hipFree(l->st_diag));
+        l->st_diag = nullptr;
+    }
+    return JSORB_OK;
+}
+int jsorb_copy_stereo_diagnostics(const jsorb_extractor *l, int image, int32_t *dst)
+{
+    if (!check_image(l, image) || !l->stereo_done || !dst || !l->st_diag) return JSORB_ERR_STATE;
+    const int n = jsorb_n_keypoints(l, image);
+    if (n <= 0) return JSORB_OK;
+    return hipMemcpy(dst, l->st_diag + (size_t)image * l->g.T * JSORB_STEREO_DIAG_INTS, (size_t)n * JSORB_STEREO_DIAG_INTS * 4, hipMemcpyDeviceToHost) == hipSuccess ? JSORB_OK : JSORB_ERR_HIP;
+}
+
 int jsorb_gather_counts_async(jsorb_extractor *l, jsorb_extractor *r, int32_t *dev_dst)
 {
     if (!l || !r || !dev_dst) return JSORB_ERR_INVALID;
@@ -1578,7 +1603,7 @@ int jsorb_stereo_match(jsorb_extractor *l, jsorb_extractor *r, float mb, float m
     if (jsorb_spec_state *S = l->spec) {
         // this very match may already be on the GPU, enqueued behind the two extracts (struct jsorb_spec_state)
         std::lock_guard<std::mutex> lk(S->mu);
-        adopt = S->l == l && S->r == r && S->inflight && S->l_seq == l->spec_seq && S->r_seq == r->spec_seq && S->mb == mb && S->mbf == mbf &&
+        adopt = !l->st_diag && S->l == l && S->r == r && S->inflight && S->l_seq == l->spec_seq && S->r_seq == r->spec_seq && S->mb == mb && S->mbf == mbf &&
                 S->th_high == th_high && S->th_low == th_low && l->extracted && r->extracted && l->n_images == 1 && r->n_images == 1 && !l->stereo_done;
         if (adopt) { S->inflight = false; S->n_adopted++; }
     }

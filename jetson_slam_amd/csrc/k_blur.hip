@@ -38,8 +38,11 @@ __constant__ unsigned c_gauss_bits[7][4] = {
 
 #define BLUR_SW 8              // output pixels per lane and row
 #ifndef BLUR_RB_MAX
-#define BLUR_RB_MAX 32         // output rows per lane; per level the host evens the bands out (fill_blur_layout)
+#define BLUR_RB_MAX 16         // output rows per lane; per level the host evens the bands out (fill_blur_layout).  Measured at C2 (pairs/s): 32 rows
+                               // 117.2 k, 16 rows 120.0 k - six halo rows per band cost 37 % more conversions and horizontal sums, but a wave
+                               // of 32-row bands lives for a third of the whole launch and the launch ends in a long, thin tail
 #endif
+static_assert(BLUR_RB_MAX % 16 == 0 && BLUR_RB_MAX <= 32, "the per-lane row masks are read back as 16-byte units; list entries hold 5 bits of row");
 #define BLUR_THREADS 256
 #define BLUR_AMB_CAP 768       // listed undecided pixels per WAVE (of <= 64 * 8 * BLUR_RB_MAX = 16384) before the dense exact path takes over
 
@@ -87,7 +90,10 @@ int blur_level_blocks(const LevelDesc &lv) { return (lv.blur_bx * lv.blur_by + B
 
 typedef unsigned blur_u4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(BLUR_THREADS) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *__restrict__ ctab, int n_images)
+#ifndef BLUR_MIN_WAVES
+#define BLUR_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *__restrict__ ctab, int n_images)
 {
     __shared__ __align__(16) unsigned char s_mask[BLUR_THREADS * BLUR_RB_MAX];      // per lane: one byte per output row, bit k = pixel k undecided
     __shared__ unsigned short s_list[BLUR_THREADS / 64][BLUR_AMB_CAP];

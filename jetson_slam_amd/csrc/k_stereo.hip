@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
                                                const int *__restrict__ row_tabR,
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
-                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs)
+                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag)
 {
     __shared__ int s_lvi[JSORB_MAX_LEVELS][12];      // th, nth, row_tab_off, W, pitch, img_off, 1/th magic, tw, ntw, tile_off, 1/tw magic (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
@@ -369,6 +369,17 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         // per-keypoint statistics; k_median reduces them per pair (per-wave global atomics on one cache line per pair
         // serialised at the L2 atomic unit and cost more than the whole matcher)
         aux[tb + i] = (n_cand & 0x7FFFFFFF) | (corr ? 0x80000000u : 0u);
+        if (diag) {
+            // inspection (jsorb_set_stereo_diagnostics): the intermediate results the reference keeps per left keypoint - best right index and
+            // Hamming distance of K12's arg-min (orb_stereo_match.cu:241-256: -1 / th_high when no candidate is closer than th_high) and the 11
+            // L1 sums of K13 + gemv (:294-470; only meaningful where the window search ran: bit 31 of aux)
+            int *dg = diag + (size_t)(tb + i) * JSORB_STEREO_DIAG_INTS;
+            const int bd = best_key == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(best_key >> 20);
+            dg[0] = bd < sa.th_high ? (int)(best_key & 0xFFFFFu) : -1;
+            dg[1] = bd < sa.th_high ? bd : sa.th_high;
+#pragma unroll
+            for (int q = 0; q < 11; q++) dg[2 + q] = corr ? acc[q] : -1;
+        }
     }
 }
 
@@ -578,10 +589,10 @@ void launch_gather_counts(const int *countsL, const int *countsR, const int *sta
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
-                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s)
+                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag)
 {
     hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + SKPW - 1) / SKPW, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
-                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs);
+                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag);
 }
 
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,

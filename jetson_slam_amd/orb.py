@@ -31,7 +31,7 @@ EXPORTS = [
     "jsorb_copy_descriptors", "jsorb_n_levels", "jsorb_level_dims", "jsorb_level_tiles", "jsorb_total_tiles", "jsorb_scale",
     "jsorb_inv_scale", "jsorb_level_image_device", "jsorb_copy_level_image", "jsorb_copy_tile_candidates", "jsorb_copy_angles",
     "jsorb_stereo_match", "jsorb_stereo_match_batch_async", "jsorb_stereo_uright_device", "jsorb_stereo_depth_device",
-    "jsorb_copy_stereo", "jsorb_copy_stereo_l1", "jsorb_set_speculative_stereo", "jsorb_speculative_stereo_stats", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
+    "jsorb_copy_stereo", "jsorb_copy_stereo_l1", "jsorb_set_stereo_diagnostics", "jsorb_copy_stereo_diagnostics", "jsorb_set_speculative_stereo", "jsorb_speculative_stereo_stats", "jsorb_gather_counts_async", "jsorb_set_stream", "jsorb_get_stream", "jsorb_stream_wait_done", "jsorb_enable_kernel_timing", "jsorb_kernel_time",
     "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
     "jsorb_unpack_frame", "jsorb_assign_features_to_grid", "jsorb_copy_level_mask",
     "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
@@ -113,6 +113,8 @@ def load_library(path=None):
         "jsorb_copy_stereo": (I, [P, I, P, P, C.POINTER(JsorbStereoStats)]),
         "jsorb_gather_counts_async": (I, [P, P, P]),
         "jsorb_copy_stereo_l1": (I, [P, I, P]),
+        "jsorb_set_stereo_diagnostics": (I, [P, I]),
+        "jsorb_copy_stereo_diagnostics": (I, [P, I, P]),
         "jsorb_set_speculative_stereo": (I, [P, I]),
         "jsorb_speculative_stereo_stats": (I, [P, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "jsorb_set_stream": (I, [P, P]),
@@ -416,6 +418,21 @@ def stereo_l1(left, image=0):
     out = np.full(max(n, 1), -1, np.int32)
     left._chk(left._lib.jsorb_copy_stereo_l1(left.handle, image, out.ctypes.data))
     return out[:n]
+
+
+def set_stereo_diagnostics(left, on=True):
+    """keep the matcher's intermediate results of the following matches (stereo_diagnostics)"""
+    left._chk(left._lib.jsorb_set_stereo_diagnostics(left.handle, 1 if on else 0))
+
+
+def stereo_diagnostics(left, image=0):
+    """(best_right[N], best_dist[N], l1_sums[N, 11]) of the last match: K12's arg-min per left keypoint (-1 / th_high: none) and the 11 L1 window
+    sums of K13 (-1 where no window search ran) - what the reference keeps on the host between its two kernels"""
+    n = left.n_keypoints(image)
+    out = np.full((max(n, 1), 13), -1, np.int32)
+    left._chk(left._lib.jsorb_copy_stereo_diagnostics(left.handle, image, out.ctypes.data))
+    out = out[:n]
+    return out[:, 0].copy(), out[:, 1].copy(), out[:, 2:].copy()
 
 
 def gather_counts_async(left, right, dev_dst_ptr):
