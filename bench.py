@@ -162,6 +162,32 @@ def main():
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    # Rank placement (jetson_slam_amd/placement.py): the rank binds itself to the cores of its GPU's NUMA node BEFORE it allocates pinned host
+    # memory or starts threads (first touch puts the pages there; 8 ranks x ~52 GB/s of pinned reads would otherwise cross the socket link for
+    # half of the ranks).  At N > 1 right here; at N = 1 only around the host-streamed leg, so that the CPU baseline keeps every core it is granted.
+    placement_info = [None]
+
+    def apply_placement():
+        if placement_info[0] is not None or os.environ.get("JSORB_NO_PLACEMENT"):
+            return placement_info[0]
+        from jetson_slam_amd import placement
+        try:
+            n_dev = torch.cuda.device_count()
+            single = bool(os.environ.get("JSORB_BENCH_SINGLE_DEVICE"))
+            addrs = []
+            for r_ in range(world):
+                pr = torch.cuda.get_device_properties(0 if single else min(r_, n_dev - 1))
+                addrs.append(placement.pci_address(pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+            n_share, k_share = placement.ranks_sharing_node(addrs)[rank % world]
+            info = placement.bind(placement.plan(addrs[rank % world], sorted(os.sched_getaffinity(0)), k_share, n_share))
+        except Exception as e:                         # never let placement break a run
+            info = {"bound": False, "note": "placement failed: %s" % str(e)[:120]}
+        placement_info[0] = info
+        return info
+
+    if world > 1:
+        apply_placement()
     dist = None
     rccl_init_s = None
     if world > 1:
@@ -301,7 +327,8 @@ def main():
     from oracle import pyoracle as po
     okw = dict(height=H, width=W, n_levels=L, tile_h=tile, tile_w=tile, th_fast_max=th)
     cores = usable_cores()
-    o_digest, o_counts = po.pairs_digest(left_u, right_u, mb, bf, max(1, cores // world), **okw)
+    bound = bool(placement_info[0] and placement_info[0].get("bound"))      # a bound rank's affinity mask already is its share of the host
+    o_digest, o_counts = po.pairs_digest(left_u, right_u, mb, bf, max(1, cores if bound else cores // world), **okw)
     n_bad = 0
     for i in range(n_unique):
         a, b = groups[i // per]
@@ -392,6 +419,10 @@ def main():
         hs_multi = {"value": round(sum(v[0] for v in vals), 1), "unit": "stereo pairs/s", "per_gpu": [round(v[0], 1) for v in vals],
                     "pcie_gb_per_s_per_gpu": [round(v[1], 2) for v in vals], "pcie_gb_per_s": round(sum(v[1] for v in vals), 2),
                     "sample": "all %d ranks at the same time, each: %s" % (world, hs["sample"])}
+    placements = None
+    if world > 1:                                       # what every rank bound itself to (rank order)
+        placements = [None] * world
+        dist.all_gather_object(placements, placement_info[0])
     if rank == 0:
         ab, Ppx, T = algo_bytes_per_pair(exl)
         per_step_ms = {k: v[2] for k, v in kt.items()}
@@ -438,6 +469,7 @@ def main():
             # the device-resident handles stay alive: handles created right after others of the process were destroyed measured 17 %
             # less in this regime (57.9 k against 70 k pairs/s, tools/micro/hs_mimic.py dev_closed / dev_closelate - device memory handed
             # back to the runtime and allocated again), which is a property of the allocation history, not of the regime
+            apply_placement()                           # pinned buffers of the streamed leg: allocated by a thread that sits on the GPU's NUMA node
             host_streamed = measure_host_streamed(orb, torch, cfg, left_u, right_u, dev)
             for h in handles:
                 h.close()
@@ -469,6 +501,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "host_streamed": host_streamed, "frame_latency_us": frame_latency, "c4_batch64": c4,
             "other_configs": other, "rccl_init_s": None if rccl_init_s is None else round(rccl_init_s, 3),
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+            "placement": placements if world > 1 else [placement_info[0]],
         }
         print(json.dumps(out), flush=True)
     if world > 1:

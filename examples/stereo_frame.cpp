@@ -38,8 +38,12 @@ int main(int argc, char **argv)
         kpL.to_cpu(); kpR.to_cpu(); dL.to_cpu(); dR.to_cpu();           // Frame.cpp:119-122
         const int nl = kpL.count_ / 6, nr = kpR.count_ / 6;
         // Frame::ComputeStereoMatches exactly as the reference writes it (Frame.cpp:780-803): members of orb_cuda::ORB_GPU
-        struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };       // stands in for cv::KeyPoint
+        struct Point2f { float x, y; };
+        struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id; };      // stands in for cv::KeyPoint (same members, same layout)
         std::vector<KeyPoint> mvKeysRef(nl), mvKeysRightRef(nr);
+        // Frame.cpp:140-160: the SoA of extract() unpacked into cv::KeyPoint (every int converted to float)
+        for (int i = 0; i < nl; i++) mvKeysRef[i] = KeyPoint{{(float)kpL.cpu_data_[i], (float)kpL.cpu_data_[nl + i]}, (float)kpL.cpu_data_[5 * nl + i], 0.f, (float)kpL.cpu_data_[2 * nl + i], kpL.cpu_data_[4 * nl + i], -1};
+        for (int i = 0; i < nr; i++) mvKeysRightRef[i] = KeyPoint{{(float)kpR.cpu_data_[i], (float)kpR.cpu_data_[nr + i]}, (float)kpR.cpu_data_[5 * nr + i], 0.f, (float)kpR.cpu_data_[2 * nr + i], kpR.cpu_data_[4 * nr + i], -1};
         std::vector<float> mvuRight, mvDepth;
         const float mb = mbf / fx;
         {
@@ -47,6 +51,17 @@ int main(int argc, char **argv)
             orb_cuda::ORB_GPU &orb_exr = *exR.orb_gpu_;
             orb_exl.ORB_compute_stereo_match(100, 50, mb, mbf, orb_exl.height_, orb_exl.width_, mvKeysRef, mvKeysRightRef, mvuRight, mvDepth,
                                              dL.gpu_data(), dR.gpu_data(), orb_exl.image_, orb_exr.image_);
+        }
+        if (nl > 2) {   // the shim matches the handles' LAST extract: keypoints that are not those (here: two of them swapped) must be refused, not matched silently
+            std::vector<KeyPoint> edited(mvKeysRef);
+            std::swap(edited[0], edited[nl - 1]);
+            std::vector<float> u3, d3;
+            bool refused = false;
+            try {
+                exL.orb_gpu_->ORB_compute_stereo_match(100, 50, mb, mbf, exL.orb_gpu_->height_, exL.orb_gpu_->width_, edited, mvKeysRightRef, u3, d3, dL.gpu_data(),
+                                                       dR.gpu_data(), exL.orb_gpu_->image_, exR.orb_gpu_->image_);
+            } catch (const std::runtime_error &) { refused = true; }
+            if (!refused) { fprintf(stderr, "edited keypoints were matched instead of refused\n"); return 3; }
         }
         {   // the free-function form must give the same bits
             std::vector<float> u2, d2;
@@ -64,6 +79,19 @@ int main(int argc, char **argv)
             kpL.to_cpu_async();
             kpL.sync_stream();
             if (memcmp(host_side.data(), kpL.cpu_data(), sizeof(int) * kpL.count_)) { fprintf(stderr, "SyncedMem device copy differs from host copy\n"); return 3; }
+        }
+        {   // copies of a SyncedMem (Frame is copied and assigned every frame) share the buffers AND the "host copy is fresh" knowledge: a device-side
+            // write through one alias must make to_cpu() of every other alias copy again
+            orb_cuda::SyncedMem<int> a;
+            a.resize(64);
+            for (int i = 0; i < 64; i++) a.cpu_data_[i] = i + 1;
+            a.to_gpu();
+            a.set_host_fresh(true);                // what ORB_GPU::extract leaves behind
+            orb_cuda::SyncedMem<int> b(a);
+            b.set_zero_gpu();                      // the alias changes the device side
+            a.to_cpu();                            // must not take the shortcut
+            for (int i = 0; i < 64; i++)
+                if (a.cpu_data_[i] != 0) { fprintf(stderr, "SyncedMem alias: stale host copy after a device-side write through a copy\n"); return 3; }
         }
         FILE *f = fopen(argv[10], "wb");
         fwrite(&nl, 4, 1, f); fwrite(&nr, 4, 1, f);

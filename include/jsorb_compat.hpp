@@ -108,7 +108,14 @@ struct SyncedBufferCache {
 // original (a reference count decides who frees); an object that has to grow while it shares leaves the old buffers to the others.
 template <typename Dtype>
 class SyncedMem {
-    struct Owner { void *cpu = nullptr, *gpu = nullptr; cudaStream_t stream = nullptr; size_t bytes = 0; bool pitched = false; std::atomic<bool> stream_used{false}; std::atomic<int> refs{1}; };
+    // shared by every copy of a SyncedMem: the buffers, the private stream, and what is known about them - whether the host side is current
+    // (host_fresh: a copy that writes the device side invalidates it for ALL aliases; round-3 review) and whether work the library cannot see
+    // may still be using the device buffer (foreign: the caller took gpu_data() or queued a copy on a stream of its own)
+    struct Owner {
+        void *cpu = nullptr, *gpu = nullptr; cudaStream_t stream = nullptr; size_t bytes = 0; bool pitched = false;
+        std::atomic<bool> stream_used{false}, host_fresh{false}, foreign{false};
+        std::atomic<int> refs{1};
+    };
 
 public:
     SyncedMem() : count_(0), capacity_(0), cpu_data_(nullptr), gpu_data_(nullptr), pitch_(0), cu_stream_(nullptr), cu_error_(0), own_(new Owner)
@@ -119,7 +126,7 @@ public:
     ~SyncedMem() { release(); }
     SyncedMem(const SyncedMem &o)
         : count_(o.count_), capacity_(o.capacity_), cpu_data_(o.cpu_data_), gpu_data_(o.gpu_data_), pitch_(o.pitch_), cu_stream_(o.cu_stream_),
-          cu_error_(o.cu_error_), host_fresh_(o.host_fresh_), own_(o.own_)
+          cu_error_(o.cu_error_), own_(o.own_)
     {
         if (own_) own_->refs.fetch_add(1);
     }
@@ -129,12 +136,12 @@ public:
         if (o.own_) o.own_->refs.fetch_add(1);
         release();
         count_ = o.count_; capacity_ = o.capacity_; cpu_data_ = o.cpu_data_; gpu_data_ = o.gpu_data_; pitch_ = o.pitch_; cu_stream_ = o.cu_stream_;
-        cu_error_ = o.cu_error_; host_fresh_ = o.host_fresh_; own_ = o.own_;
+        cu_error_ = o.cu_error_; own_ = o.own_;
         return *this;
     }
     SyncedMem(SyncedMem &&o) noexcept
         : count_(o.count_), capacity_(o.capacity_), cpu_data_(o.cpu_data_), gpu_data_(o.gpu_data_), pitch_(o.pitch_), cu_stream_(o.cu_stream_),
-          cu_error_(o.cu_error_), host_fresh_(o.host_fresh_), own_(o.own_)
+          cu_error_(o.cu_error_), own_(o.own_)
     {
         o.count_ = o.capacity_ = 0; o.cpu_data_ = nullptr; o.gpu_data_ = nullptr; o.cu_stream_ = nullptr; o.own_ = nullptr;
     }
@@ -143,7 +150,7 @@ public:
         if (this == &o) return *this;
         release();
         count_ = o.count_; capacity_ = o.capacity_; cpu_data_ = o.cpu_data_; gpu_data_ = o.gpu_data_; pitch_ = o.pitch_; cu_stream_ = o.cu_stream_;
-        cu_error_ = o.cu_error_; host_fresh_ = o.host_fresh_; own_ = o.own_;
+        cu_error_ = o.cu_error_; own_ = o.own_;
         o.count_ = o.capacity_ = 0; o.cpu_data_ = nullptr; o.gpu_data_ = nullptr; o.cu_stream_ = nullptr; o.own_ = nullptr;
         return *this;
     }
@@ -151,7 +158,7 @@ public:
     void resize(int count)
     {
         count_ = count;
-        host_fresh_ = false;
+        set_host_fresh(false);
         if (capacity_ < count_) {
             capacity_ = count_;
             fresh_owner();
@@ -168,7 +175,7 @@ public:
     void resize_pitched(size_t width, size_t height)
     {
         count_ = (int)(width * height);
-        host_fresh_ = false;
+        set_host_fresh(false);
         fresh_owner();
         void *c = nullptr, *g = nullptr;
         note(jsorb_mem_alloc_host((size_t)count_ * sizeof(Dtype), &c));
@@ -179,17 +186,17 @@ public:
 
     // the caller may write through either pointer: the other side is no longer known to be current (to_cpu() then copies, as
     // synced_mem_holder.cpp:88-91 always does)
-    Dtype *cpu_data() { host_fresh_ = false; return cpu_data_; }
-    Dtype *gpu_data() { host_fresh_ = false; return gpu_data_; }
+    Dtype *cpu_data() { set_host_fresh(false); return cpu_data_; }
+    Dtype *gpu_data() { set_host_fresh(false); if (own_) own_->foreign.store(true); return gpu_data_; }
 
     void to_cpu(void) { to_cpu(count_); }
     void to_gpu(void) { to_gpu(count_); }
     void to_cpu(int count)
     {
-        if (host_fresh_ && count <= count_) return;      // ORBExtractor::extract already delivered the host copy with the device copy and nobody has asked for a pointer since
+        if (host_fresh() && count <= count_) return;      // ORBExtractor::extract already delivered the host copy with the device copy and nobody has asked for a pointer since
         note(jsorb_mem_d2h(cpu_data_, gpu_data_, (size_t)count * sizeof(Dtype)));
     }
-    void to_gpu(int count) { host_fresh_ = false; note(jsorb_mem_h2d(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype))); }
+    void to_gpu(int count) { set_host_fresh(false); note(jsorb_mem_h2d(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype))); }
     void to_cpu_async(void) { to_cpu_async(cu_stream_, count_); }
     void to_gpu_async(void) { to_gpu_async(cu_stream_, count_); }
     void to_cpu_async(cudaStream_t &cu_stream) { to_cpu_async(cu_stream, count_); }
@@ -198,20 +205,20 @@ public:
     void to_gpu_async(int count) { to_gpu_async(cu_stream_, count); }
     void to_cpu_async(cudaStream_t &cu_stream, int count)
     {
-        if (host_fresh_ && count <= count_) return;
+        if (host_fresh() && count <= count_) return;
         mark_stream(cu_stream);
         note(jsorb_mem_d2h_async(cpu_data_, gpu_data_, (size_t)count * sizeof(Dtype), cu_stream));
     }
     void to_gpu_async(cudaStream_t &cu_stream, int count)
     {
-        host_fresh_ = false;
+        set_host_fresh(false);
         mark_stream(cu_stream);
         note(jsorb_mem_h2d_async(gpu_data_, cpu_data_, (size_t)count * sizeof(Dtype), cu_stream));
     }
     void sync_stream(void) { note(jsorb_mem_stream_sync(cu_stream_)); }
-    void set_zero_gpu(void) { host_fresh_ = false; note(jsorb_mem_set_zero(gpu_data_, (size_t)count_ * sizeof(Dtype))); }
-    void set_zero_gpu_async(void) { host_fresh_ = false; mark_stream(cu_stream_); note(jsorb_mem_set_zero_async(gpu_data_, (size_t)count_ * sizeof(Dtype), cu_stream_)); }
-    void set_zero_cpu(void) { host_fresh_ = false; if (cpu_data_) memset(cpu_data_, 0, (size_t)count_ * sizeof(Dtype)); }
+    void set_zero_gpu(void) { set_host_fresh(false); note(jsorb_mem_set_zero(gpu_data_, (size_t)count_ * sizeof(Dtype))); }
+    void set_zero_gpu_async(void) { set_host_fresh(false); mark_stream(cu_stream_); note(jsorb_mem_set_zero_async(gpu_data_, (size_t)count_ * sizeof(Dtype), cu_stream_)); }
+    void set_zero_cpu(void) { set_host_fresh(false); if (cpu_data_) memset(cpu_data_, 0, (size_t)count_ * sizeof(Dtype)); }
 
     // public in the reference ("//private:" is commented out there)
     int count_;
@@ -223,20 +230,24 @@ public:
     cudaError_t cu_error_;
 
     // set by ORB_GPU::extract when it fills both sides in one go (the four blocking to_cpu() of Frame.cpp:119-122 then cost nothing);
-    // cleared by anything that hands out a pointer or moves data
-    bool host_fresh_ = false;
+    // cleared by anything that hands out a pointer or moves data.  The flag lives with the shared buffers: every alias sees it.
+    void set_host_fresh(bool v) { if (own_) own_->host_fresh.store(v); }
+    bool host_fresh() const { return own_ && own_->host_fresh.load(); }
 
 private:
     Owner *own_;
     void note(int rc) { if (rc != JSORB_OK) cu_error_ = rc; }
     // work enqueued on any stream makes the buffers busy until that stream has run: the release paths wait for the private stream only when it was
     // used (work put on a FOREIGN stream is the caller's to synchronise before the object goes away, as in the reference)
-    void mark_stream(cudaStream_t st) { if (own_ && st == own_->stream) own_->stream_used.store(true); }
+    void mark_stream(cudaStream_t st) { if (!own_) return; if (st == own_->stream) own_->stream_used.store(true); else own_->foreign.store(true); }
+    // The reference frees with cudaFree / cudaFreeHost, which wait for the whole device; a recycled buffer must not reach its next user while
+    // work the library never saw (kernels on gpu_data(), copies on the caller's streams) may still touch it: one device-wide wait then
+    static void settle(Owner *o) { if (o->foreign.load()) { jsorb_mem_device_sync(); o->foreign.store(false); } }
     static void destroy(Owner *o)
     {
         detail::SyncedBufferCache::get().give_stream(o->stream, o->stream_used.load());      // (waits for the stream's work first, if it ever had any)
         if (o->pitched) { if (o->cpu) jsorb_mem_free_host(o->cpu); if (o->gpu) jsorb_mem_free_device(o->gpu); }
-        else if (o->cpu || o->gpu) detail::SyncedBufferCache::get().give(o->bytes, o->cpu, o->gpu);
+        else if (o->cpu || o->gpu) { settle(o); detail::SyncedBufferCache::get().give(o->bytes, o->cpu, o->gpu); }
         delete o;
     }
     void release()
@@ -252,9 +263,11 @@ private:
             if (own_->pitched) { if (own_->cpu) jsorb_mem_free_host(own_->cpu); if (own_->gpu) jsorb_mem_free_device(own_->gpu); }
             else if (own_->cpu || own_->gpu) {
                 if (own_->stream && own_->stream_used.load()) jsorb_mem_stream_sync(own_->stream);
+                settle(own_);
                 detail::SyncedBufferCache::get().give(own_->bytes, own_->cpu, own_->gpu);
             }
             own_->cpu = own_->gpu = nullptr;
+            own_->host_fresh.store(false);
         } else {
             if (own_) own_->refs.fetch_sub(1);
             own_ = new Owner;
@@ -372,7 +385,7 @@ public:
         if (n > 0 && (jsorb_copy_keypoints(handle_, 0, out_keypoints.cpu_data_) != JSORB_OK ||             // host side: from the handle's pinned mirror
                       jsorb_copy_descriptors(handle_, 0, out_keypoints_desc.cpu_data_) != JSORB_OK))
             throw std::runtime_error("jsorb: delivering the extract results failed");
-        out_keypoints.host_fresh_ = out_keypoints_desc.host_fresh_ = true;
+        out_keypoints.set_host_fresh(true); out_keypoints_desc.set_host_fresh(true);
     }
 #ifdef JSORB_WITH_OPENCV
     void extract(const cv::Mat &image, SyncedMem<int> &out_keypoints, SyncedMem<unsigned char> &out_keypoints_desc)
@@ -384,7 +397,7 @@ public:
     // ORB_GPU::ORB_compute_stereo_match (orb_gpu.hpp:218-229, orb_stereo_match.cu:105-580) with the reference's parameter list, so
     // that Frame::ComputeStereoMatches (Frame.cpp:780-803) compiles unchanged.  It matches the LAST extract of the two handles - which
     // is what mvKeys / mvKeysRight / the descriptor pointers / the two pyramids describe at that call site; the keypoint vectors are
-    // only used for their sizes (checked), the descriptor pointers are not read.  KeyPoint is cv::KeyPoint in the reference.
+    // compared with the handles' own keypoints (below), the descriptor pointers are not read.  KeyPoint is cv::KeyPoint in the reference.
     template <class KeyPoint>
     void ORB_compute_stereo_match(int ORB_TH_HIGH, int ORB_TH_LOW, float mb, float mbf, std::vector<int> & /*octave_height*/, std::vector<int> & /*octave_width*/,
                                   std::vector<KeyPoint> &mvKeys, std::vector<KeyPoint> &mvKeysRight, std::vector<float> &mvuRight, std::vector<float> &mvDepth,
@@ -400,6 +413,32 @@ public:
         const int n = jsorb_n_keypoints(l, 0);
         if (n < 0 || (size_t)n != mvKeys.size() || (size_t)jsorb_n_keypoints(r, 0) != mvKeysRight.size())
             throw std::runtime_error("ORB_compute_stereo_match: keypoint vectors do not match the last extract of the handles");
+        // The reference READS mvKeys / mvKeysRight (orb_stereo_match.cu:119-184); this implementation matches what the handles extracted last.  A
+        // caller that filtered, reordered or edited its keypoints in between would get silently different results, so the keypoint
+        // vectors are compared with the handles' own (position and octave): all of them on the first call and in debug builds, a strided
+        // sample afterwards.  JSORB_COMPAT_NO_KEYPOINT_CHECK removes the check (two device-to-host copies of 24 N bytes per call).
+#ifndef JSORB_COMPAT_NO_KEYPOINT_CHECK
+        {
+#ifdef NDEBUG
+            const size_t stride = keypoints_checked_ ? 16 : 1;
+#else
+            const size_t stride = 1;
+#endif
+            auto same = [&](jsorb_extractor *h, const std::vector<KeyPoint> &keys, std::vector<int32_t> &soa) {
+                const size_t m = keys.size();
+                if (!m) return true;
+                soa.resize(6 * m);
+                if (jsorb_copy_keypoints(h, 0, soa.data()) != JSORB_OK) return false;
+                for (size_t i = 0; i < m; i += (i + stride < m || i + 1 == m) ? stride : m - 1 - i)      // the strided sample always includes the last one
+                    if (keys[i].pt.x != (float)soa[i] || keys[i].pt.y != (float)soa[m + i] || keys[i].octave != soa[4 * m + i]) return false;
+                return true;
+            };
+            if (!same(l, mvKeys, check_soa_) || !same(r, mvKeysRight, check_soa_))
+                throw std::runtime_error("ORB_compute_stereo_match: mvKeys / mvKeysRight are not the keypoints of the handles' last extract (filtered or "
+                                         "reordered?) - this implementation matches the last extract, see INTEGRATION.md");
+            keypoints_checked_ = true;
+        }
+#endif
         mvuRight.resize(mvKeys.size(), -1.0f);          // orb_stereo_match.cu:496-497 (resize keeps earlier contents; the ABI call overwrites all n)
         mvDepth.resize(mvKeys.size(), -1.0f);
         float dummy = -1.0f;
@@ -416,6 +455,8 @@ public:
     ImagePyramid image_;
     jsorb_stereo_stats last_stereo_stats_{};
     bool speculation_requested_ = false;
+    bool keypoints_checked_ = false;
+    std::vector<int32_t> check_soa_;
 
 private:
     jsorb_extractor *handle_ = nullptr;

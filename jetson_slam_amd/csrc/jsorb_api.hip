@@ -1702,6 +1702,7 @@ int jsorb_mem_stream_create(void **stream)
 }
 int jsorb_mem_stream_destroy(void *stream) { if (stream) MEMCHK(hipStreamDestroy((hipStream_t)stream)); return JSORB_OK; }
 int jsorb_mem_stream_sync(void *stream) { MEMCHK(hipStreamSynchronize((hipStream_t)stream)); return JSORB_OK; }
+int jsorb_mem_device_sync(void) { MEMCHK(hipDeviceSynchronize()); return JSORB_OK; }
 int jsorb_mem_h2d(void *d, const void *h, size_t n) { if (n) MEMCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return JSORB_OK; }
 int jsorb_mem_d2h(void *h, const void *d, size_t n) { if (n) MEMCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return JSORB_OK; }
 int jsorb_mem_d2d(void *d, const void *s, size_t n) { if (n) MEMCHK(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice)); return JSORB_OK; }
