@@ -73,7 +73,7 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     o += (size_t)d.score_w * d.score_rows * 2;
     o = (o + 15) & ~(size_t)15;
     d.off_list = o;
-    o += (size_t)d.list_cap * DET_NW * 2;
+    o += (size_t)(d.list_cap + 64) * DET_NW * 2;      // + 64 dump slots per wave: lanes without a survivor store there (no exec masking around the list appends)
     o = (o + 15) & ~(size_t)15;
     d.off_colkey = o;
     o += 128 * 4;
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     const int sub = two_rows ? (lane >> 5) : 0;
     const int q = two_rows ? (lane & 31) : lane;
     const int rows_per_step = two_rows ? 2 : 1;
-    unsigned short *my_list = s_list + wave * L.list_cap;
+    unsigned short *my_list = s_list + wave * (L.list_cap + 64);
+    const int dump_idx = L.list_cap + lane;               // where a lane without a survivor stores (never read)
     int n_mine = 0;                                       // wave-uniform
     // everything that depends only on the lane's column is loop-invariant: the dword it owns and the nibble of its pixels
     // that lie inside [c_lo, c_hi) (interior columns of this tile group)
@@ -478,7 +479,9 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
             // (entry = e0 + t as a 32-bit addition: the 16-bit one the compiler picks for the truncated value issues at half the rate)
             unsigned ent = (unsigned)e0;
             if (t) asm("v_add_u32_e32 %0, %1, %2" : "=v"(ent) : "n"(t), "v"(e0));
-            if (keep) (my_list + n_mine)[pos] = (unsigned short)ent;           // (scalar base + lane rank: no move of n_mine into a vector register)
+            // every lane stores: survivors at the list's tail + their rank, the others into the wave's dump slots.  Masking the store instead
+            // (s_and_saveexec / s_cbranch_execz / s_or exec) costs three scalar instructions per slot, and the scalar pipe is as busy as the vector pipes here
+            my_list[keep ? n_mine + (int)pos : dump_idx] = (unsigned short)ent;
             n_mine += __popcll(bal);
         }
     }
