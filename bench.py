@@ -129,7 +129,9 @@ def main():
     ap.add_argument("--min-time", type=float, default=2.0, help="repeat the block of --steps steps until this many seconds are measured; the median block is reported")
     ap.add_argument("--tile", type=int, default=0, help="override the configuration's tile size (default: the yaml-faithful one)")
     ap.add_argument("--seed-base", type=int, default=1, help="seed of the first synthetic pair (parity soaks over other pairs: tools/micro/soak_bench.sh)")
-    ap.add_argument("--unique", type=int, default=0, help="unique synthetic pairs per rank (default: one per pair of the step, at most 128)")
+    ap.add_argument("--unique", type=int, default=0, help="unique synthetic pairs per rank and input set (default: one per pair of the step, at most 128)")
+    ap.add_argument("--input-sets", type=int, default=0, help="input sets rotated through the steps (default: 4 = 370 MB of level-0 data per GPU at the default c2 step - more than "
+                    "the 256 MiB Infinity Cache, so that no step re-reads its images from the cache; 1 for the other configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-streamed / frame-latency / C4 side measurements")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
@@ -225,12 +227,19 @@ def main():
     from jetson_slam_amd.batch import shard_range
     p_first, p_end = shard_range(P * world, rank, world)
     assert p_end - p_first == P
-    host_pairs = [synth_stereo_pair(args.seed_base + p_first + i, H, W) for i in range(n_unique)]
-    left_u = np.stack([p[0] for p in host_pairs])
-    right_u = np.stack([p[1] for p in host_pairs])
-    idx = np.arange(P) % n_unique
-    left_d = torch.from_numpy(left_u[idx]).to(dev)
-    right_d = torch.from_numpy(right_u[idx]).to(dev)
+    # input sets: step k works on set k mod n_sets (different synthetic pairs in every set), so that consecutive steps do not find their
+    # images in the 256 MiB Infinity Cache
+    n_sets = args.input_sets if args.input_sets > 0 else (4 if (args.config == "c2" and args.tile <= 0 and not args.single_stream and not strong and P >= 64) else 1)
+    sets_u, sets_d = [], []
+    for si in range(n_sets):
+        host_pairs = [synth_stereo_pair(args.seed_base + si * P * world + p_first + i, H, W) for i in range(n_unique)]
+        lu, ru = np.stack([p[0] for p in host_pairs]), np.stack([p[1] for p in host_pairs])
+        idx = np.arange(P) % n_unique
+        sets_u.append((lu, ru))
+        sets_d.append((torch.from_numpy(lu[idx]).to(dev), torch.from_numpy(ru[idx]).to(dev)))
+    left_u, right_u = sets_u[0]
+    left_d, right_d = sets_d[0]
+    cur_set = [0]
 
     G = max(1, args.groups)
     while P % G:
@@ -261,10 +270,13 @@ def main():
     step_no = [0]
     mb = bf / fx
 
-    def step():
+    def step(which=None):
+        si = cur_set[0] if which is None else which
+        cur_set[0] = (si + 1) % n_sets
+        ld, rd = sets_d[si]
         for gi, (a, b) in enumerate(groups):
-            a.extract_batch_device_async(left_d[gi * per:].data_ptr(), H * W, W, per, keep=left_d)
-            b.extract_batch_device_async(right_d[gi * per:].data_ptr(), H * W, W, per, keep=right_d)
+            a.extract_batch_device_async(ld[gi * per:].data_ptr(), H * W, W, per, keep=ld)
+            b.extract_batch_device_async(rd[gi * per:].data_ptr(), H * W, W, per, keep=rd)
         for a, b in groups:
             orb.stereo_match_batch_async(a, b, mb, bf)
         if world > 1:   # the one collective of the path: per-pair (N_left, N_right, N_matched), <2 KB per rank
@@ -328,15 +340,18 @@ def main():
     okw = dict(height=H, width=W, n_levels=L, tile_h=tile, tile_w=tile, th_fast_max=th)
     cores = usable_cores()
     bound = bool(placement_info[0] and placement_info[0].get("bound"))      # a bound rank's affinity mask already is its share of the host
-    o_digest, o_counts = po.pairs_digest(left_u, right_u, mb, bf, max(1, cores if bound else cores // world), **okw)
     n_bad = 0
-    for i in range(n_unique):
-        a, b = groups[i // per]
-        j = i % per
-        u, d, st = orb.stereo_result(a, j)
-        got = po.digest_arrays([a.keypoints(j), a.descriptors(j), b.keypoints(j), b.descriptors(j), u, d])
-        if got != int(o_digest[i]) or [a.n_keypoints(j), b.n_keypoints(j), st["n_final"]] != o_counts[i].tolist():
-            n_bad += 1
+    for si in range(n_sets):                 # every input set once more (untimed), every unique pair of it against the oracle; the last set stays in the handles
+        step(si)
+        fence()
+        o_digest, o_counts = po.pairs_digest(sets_u[si][0], sets_u[si][1], mb, bf, max(1, cores if bound else cores // world), **okw)
+        for i in range(n_unique):
+            a, b = groups[i // per]
+            j = i % per
+            u, d, st = orb.stereo_result(a, j)
+            got = po.digest_arrays([a.keypoints(j), a.descriptors(j), b.keypoints(j), b.descriptors(j), u, d])
+            if got != int(o_digest[i]) or [a.n_keypoints(j), b.n_keypoints(j), st["n_final"]] != o_counts[i].tolist():
+                n_bad += 1
     parity_local = n_bad == 0
     counts_ok = True
     if world > 1:
@@ -443,14 +458,14 @@ def main():
                 traffic_source = tj.get("_source", "profiles/hbm_traffic.json") + " (builder-measured rocprofv3 PMC pass, NOT measured in this run)"
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "bound_note": "the contract's roofline is HBM bandwidth; what binds this integer / bitwise path is vector-instruction issue (bound_actual, valu_issue_frac)", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_pair": ab, "pairs_per_launch": units,
                 "pipeline_achieved": round(ab * pairs_per_s / world / 1e9, 1),
                 "pipeline_frac": round(ab * pairs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step_ms.items()}}
         props = torch.cuda.get_device_properties(dev)
-        vv = valu_view(args.config if args.tile <= 0 else "", pairs_per_s / world, props.multi_processor_count, 2.4e9)
+        vv = valu_view(args.config if args.tile <= 0 else "", pairs_per_s / world, props.multi_processor_count, props.clock_rate * 1e3 if getattr(props, "clock_rate", 0) else 2.4e9)
         if vv:
             roof.update(vv)
         if not args.no_extras:
@@ -491,13 +506,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD_NAMES[args.config] + (" [tile overridden: %d]" % args.tile if args.tile > 0 else "") + (" (cap %d kp/image)" % T) +
                                    ("; BASELINE C4: %d pairs per step sharded over %d GPU(s)" % (args.pairs_total, world) if strong else ""),
-                       "name": args.config, "pairs_per_gpu_per_step": P, "pairs_per_step_total": P * world, "unique_pairs_per_gpu": n_unique,
+                       "name": args.config, "pairs_per_gpu_per_step": P, "pairs_per_step_total": P * world, "unique_pairs_per_gpu": n_unique * n_sets, "input_sets": n_sets,
                        "handle_pairs": G, "library_lanes": "up to 4 HIP streams per handle (>= ~7 Mpx per lane)", "keypoints_image0": n0,
-                       "inputs": "device-resident u8",
+                       "inputs": "device-resident u8; %d input set(s) of %d pairs rotated step by step = %.0f MB of level-0 images per GPU (Infinity Cache: 256 MiB)"
+                                 % (n_sets, P, n_sets * P * 2 * H * W / 1e6),
                        "parallelism": "independent pairs sharded over %d GPU(s); RCCL all_gather of counts only" % world},
             "timing": {"blocks": len(blocks), "block_steps": args.steps, "measured_s": round(sum(blocks), 3), "statistic": "median block, max over ranks",
                        "block_ms_min": round(min(blocks) * 1e3, 3), "block_ms_max": round(max(blocks) * 1e3, 3)},
-            "parity_vs_oracle": parity, "parity_pairs_checked": n_unique * world, "gathered_counts_ok": counts_ok if world > 1 else None,
+            "parity_vs_oracle": parity, "parity_pairs_checked": n_unique * n_sets * world, "gathered_counts_ok": counts_ok if world > 1 else None,
             "roofline": roof, "cpu_baseline": cpu, "host_streamed": host_streamed, "frame_latency_us": frame_latency, "c4_batch64": c4,
             "other_configs": other, "rccl_init_s": None if rccl_init_s is None else round(rccl_init_s, 3),
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
@@ -530,19 +546,39 @@ def measure_copy_peak(torch, dev, gib=1.0, reps=6):
 
 
 def valu_view(config, pairs_per_s, n_cus, clock_hz):
-    """What actually bounds the path: vector-ALU issue.  SQ_INSTS_VALU per kernel launch comes from the builder's rocprofv3 PMC pass
-    (profiles/valu_counters.json, condensed from profiles/r03_sq_counters*.csv) - NOT measured in this run; a SIMD issues at most one
-    VALU wave-instruction per 4 clocks."""
-    path = os.path.join(ROOT, "profiles", "valu_counters.json")
+    """What actually bounds the path: vector-ALU issue (roofline.bound_actual).  Per kernel launch, SQ_INSTS_VALU and the stand-alone launch duration come
+    from the builder's rocprofv3 passes (profiles/valu_counters.json), the mean issue cost of a kernel's vector instructions from its assembly
+    (profiles/valu_mix.json: plain 32-bit arithmetic issues every 2 clocks per SIMD, packed / permute / convert / compare instructions every 4,
+    profiles/r04_valu_rate.txt).  Both files carry the digest of the kernel sources they were made from: if it is not the digest of THIS build, nothing
+    is reported.  NOT measured in this run - the run contributes pairs/s only."""
     try:
-        tj = json.load(open(path))
+        from jetson_slam_amd import build as jb
+        tj = json.load(open(os.path.join(ROOT, "profiles", "valu_counters.json")))
+        mj = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+        sha = jb.csrc_sha256()
+        if tj.get("_csrc_sha256") != sha or mj.get("_csrc_sha256") != sha:
+            return {"valu_note": "profiles/valu_counters.json / valu_mix.json were made from other kernel sources than this build: not reported"}
         k = tj[config]
-        per_pair = (2.0 * sum(v for n, v in k["extract_side"].items()) + sum(v for n, v in k["stereo_side"].items())) / float(k["_pairs_per_launch"])
-        peak = n_cus * 4 * clock_hz / 4.0                     # VALU wave-instructions per second the chip can issue
-        return {"valu_wave_instr_per_pair": round(per_pair), "valu_wave_instr_per_128_pairs": round(per_pair * 128),
-                "valu_issue_frac": round(per_pair * pairs_per_s / peak, 4),
-                "valu_issue_peak": "%d CUs x 4 SIMDs x %.2f GHz / 4 clk" % (n_cus, clock_hz / 1e9),
-                "valu_source": tj.get("_source", "profiles/valu_counters.json") + " (builder-measured rocprofv3 PMC pass, NOT measured in this run)"}
+        ppl = float(k["_pairs_per_launch"])
+        simd_hz = n_cus * 4 * clock_hz                        # SIMD-clocks per second of the chip
+        per_pair_instr, per_pair_clk4, per_pair_clkmix, per_kernel = 0.0, 0.0, 0.0, {}
+        for side, mult in (("extract_side", 2.0), ("stereo_side", 1.0)):
+            for name, instr in k[side].items():
+                mix = mj["kernels"].get(name, {}).get("clk_per_valu_instr", 4.0)
+                per_pair_instr += mult * instr / ppl
+                per_pair_clk4 += mult * instr * 4.0 / ppl
+                per_pair_clkmix += mult * instr * mix / ppl
+                us = k.get("avg_us", {}).get(name)
+                per_kernel[name] = {"valu_instr_per_launch": instr, "clk_per_valu_instr": mix,
+                                    "own_valu_bound_frac": None if not us else round(instr * mix / (simd_hz * us * 1e-6), 3)}
+        return {"bound_actual": "valu_issue",
+                "valu_wave_instr_per_pair": round(per_pair_instr), "valu_wave_instr_per_128_pairs": round(per_pair_instr * 128),
+                "valu_issue_frac": round(per_pair_clkmix * pairs_per_s / simd_hz, 4),
+                "valu_issue_frac_all_4clk": round(per_pair_clk4 * pairs_per_s / simd_hz, 4),
+                "valu_issue_peak": "%d CUs x 4 SIMDs x %.2f GHz; issue cost per instruction class from profiles/r04_valu_rate.txt (2 / 4 / 8 clk), per-kernel mix from "
+                                   "profiles/valu_mix.json (static, loop-depth weighted); _all_4clk prices every instruction at 4 clk" % (n_cus, clock_hz / 1e9),
+                "per_kernel": per_kernel,
+                "valu_source": tj.get("_source", "profiles/valu_counters.json") + " (builder-measured rocprofv3 passes, NOT measured in this run; digest of the kernel sources checked)"}
     except Exception:
         return None
 
@@ -641,15 +677,16 @@ def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seco
            "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()}}
     if not tile_override:
         props = torch.cuda.get_device_properties(dev)
-        vv = valu_view(name, pps, props.multi_processor_count, 2.4e9)
-        if vv:
+        vv = valu_view(name, pps, props.multi_processor_count, props.clock_rate * 1e3 if getattr(props, "clock_rate", 0) else 2.4e9)
+        if vv and "valu_issue_frac" in vv:
             out["valu_issue_frac"] = vv["valu_issue_frac"]
+            out["valu_issue_frac_all_4clk"] = vv["valu_issue_frac_all_4clk"]
             out["valu_wave_instr_per_pair"] = vv["valu_wave_instr_per_pair"]
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             kname = "k_compact_flat" if dom == "k_compact" else dom
             out["traffic"] = tj.get(name, {}).get(kname)
-            out["traffic_note"] = "bytes per launch of %d %s, builder-measured rocprofv3 PMC pass (profiles/r03_hbm_traffic.json), NOT measured in this run" % (
+            out["traffic_note"] = "bytes per launch of %d %s, builder-measured rocprofv3 PMC pass (profiles/hbm_traffic.json), NOT measured in this run" % (
                 P, "pairs" if dom in ("k_stereo", "k_median") else "images")
         except Exception:
             pass

@@ -240,3 +240,30 @@ def test_three_dimensional_grid_enumerates_the_same_image_block_pairs():
                         if b < n:
                             seen.append((b, blk))
             assert sorted(seen) == [(b, k) for b in range(n) for k in range(nb)]
+
+
+def test_six_bit_early_rejects_accept_a_superset_for_every_threshold():
+    """k_detect.hip detect_swar6_threshold (round 4): with q(x) = x >> 2 and t4 = (th + 1) >> 2, `p > v + th` implies bit 7 of q(p) + (128 - t4 - q(v))
+    and `p < v - th` implies bit 7 of (128 - t4 + q(v)) - q(p); both sums stay inside a byte, so four pixels share a dword without carries.  The host
+    checks this exhaustively before it selects the 6-bit kernel; restated here for every threshold, together with the monotonicity the compass test
+    needs (more flags never turn an accepted pixel into a rejected one)."""
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_detect.hip")).read()
+    assert "(p >> 2) + (cb - (v >> 2))" in src and "(cb + (v >> 2)) - (p >> 2)" in src and "t4 < 2" in src
+    v = np.arange(256)[:, None]
+    p = np.arange(256)[None, :]
+    for th in range(0, 300):
+        thc = min(th, 256)
+        t4 = (thc + 1) >> 2
+        cb = 128 - t4
+        y = (p >> 2) + (cb - (v >> 2))
+        z = (cb + (v >> 2)) - (p >> 2)
+        assert y.min() >= 0 and y.max() <= 255 and z.min() >= 0 and z.max() <= 255 and cb - 63 >= 0 and cb + 63 <= 255
+        assert np.all(((y & 0x80) != 0)[p > v + th]) and np.all(((z & 0x80) != 0)[p < v - th])
+    # compass combination: (B4|B12)&(B0|B8) | (D4|D12)&(D0|D8) is monotone in its eight flags
+    for m in range(256):
+        f = [(m >> k) & 1 for k in range(8)]
+        acc = ((f[0] | f[1]) & (f[2] | f[3])) | ((f[4] | f[5]) & (f[6] | f[7]))
+        for k in range(8):
+            if not f[k]:
+                f2 = list(f); f2[k] = 1
+                assert (((f2[0] | f2[1]) & (f2[2] | f2[3])) | ((f2[4] | f2[5]) & (f2[6] | f2[7]))) >= acc

@@ -23,7 +23,8 @@ for cfg, t in cfgs.items():
     traffic[cfg] = h[cfg]
     traffic["_raw_kb"][cfg] = h["_raw_kb"]
     sq = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(O, t + "_sq_counters.csv")))}
-    valu[cfg] = {"_pairs_per_launch": pairs[cfg],
+    ks = {r["kernel"]: float(r["avg_us"]) for r in csv.DictReader(open(os.path.join(O, t + "_kernel_stats.csv"))) if r["kernel"].startswith("k_")}
+    valu[cfg] = {"_pairs_per_launch": pairs[cfg], "avg_us": ks,      # stand-alone launch durations of the same single-stream run shape (rocprofv3 --kernel-trace --stats)
                  "extract_side": {k: int(float(sq[k]["SQ_INSTS_VALU"])) for k in sorted(sq) if k not in ("k_stereo", "k_median")},
                  "stereo_side": {k: int(float(sq[k]["SQ_INSTS_VALU"])) for k in ("k_stereo", "k_median") if k in sq}}
     suffix = "" if cfg == "c2" else "_" + cfg
@@ -31,6 +32,9 @@ for cfg, t in cfgs.items():
     shutil.copy(os.path.join(O, t + "_sq_counters.csv"), os.path.join(P, "%s_sq_counters%s.csv" % (tag, suffix)))
 for name in ("hbm_traffic.json", tag + "_hbm_traffic.json"):
     json.dump(traffic, open(os.path.join(P, name), "w"), indent=1)
+sys.path.insert(0, ROOT)
+from jetson_slam_amd import build as jb      # noqa: E402
+valu["_csrc_sha256"] = jb.csrc_sha256()        # bench.py reports these counters only for the kernel sources they were measured on
 json.dump(valu, open(os.path.join(P, "valu_counters.json"), "w"), indent=1)
 import glob
 raw = glob.glob(os.path.join(O, tag + "_trace", "**", "*kernel_stats.csv"), recursive=True)

@@ -12,7 +12,6 @@ the kernel with.  It is a STATIC estimate (a hot path inside a rarely taken bran
 as well); the bench line therefore carries the all-4-clock figure next to it.
 
 Usage: python tools/valu_mix.py            (recompiles every kernel file to assembly with the build's flags; ~1 min)"""
-import hashlib
 import json
 import os
 import re
@@ -90,13 +89,9 @@ def main():
         subprocess.run([b._hipcc()] + b.FLAGS + b.FILE_FLAGS.get(f, []) + ["-S", "--cuda-device-only", "-o", asm, src], check=True, capture_output=True)
         res.update(kernel_mix(open(asm).read(), names))
         os.remove(asm)
-    h = hashlib.sha256()
-    for f in sorted(os.listdir(b.CSRC)):
-        if f.endswith((".hip", ".h", ".inc")):
-            h.update(open(os.path.join(b.CSRC, f), "rb").read())
     out = {"_source": "tools/valu_mix.py: static, loop-depth-weighted (10^depth) classification of every vector instruction of the kernel's gfx950 assembly "
                       "into the issue classes measured in profiles/r04_valu_rate.txt (2 / 4 / 8 clocks per wave-instruction per SIMD)",
-           "_csrc_sha256": h.hexdigest(), "kernels": res}
+           "_csrc_sha256": b.csrc_sha256(), "kernels": res}
     path = os.path.join(ROOT, "profiles", "valu_mix.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
