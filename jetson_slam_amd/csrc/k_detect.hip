@@ -274,7 +274,7 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     const int q = two_rows ? (lane & 31) : lane;
     const int rows_per_step = two_rows ? 2 : 1;
     unsigned short *my_list = s_list + wave * (L.list_cap + 64);
-    const int dump_idx = L.list_cap + lane;               // where a lane without a survivor stores (never read)
+    unsigned short *const dump_ptr = my_list + L.list_cap + lane;      // where a lane without a survivor stores (never read)
     int n_mine = 0;                                       // wave-uniform
     // everything that depends only on the lane's column is loop-invariant: the dword it owns and the nibble of its pixels
     // that lie inside [c_lo, c_hi) (interior columns of this tile group)
@@ -481,7 +481,8 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
             if (t) asm("v_add_u32_e32 %0, %1, %2" : "=v"(ent) : "n"(t), "v"(e0));
             // every lane stores: survivors at the list's tail + their rank, the others into the wave's dump slots.  Masking the store instead
             // (s_and_saveexec / s_cbranch_execz / s_or exec) costs three scalar instructions per slot, and the scalar pipe is as busy as the vector pipes here
-            my_list[keep ? n_mine + (int)pos : dump_idx] = (unsigned short)ent;
+            unsigned short *const tail = my_list + n_mine;                     // scalar
+            *(keep ? tail + pos : dump_ptr) = (unsigned short)ent;
             n_mine += __popcll(bal);
         }
     }
