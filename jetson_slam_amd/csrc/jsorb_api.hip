@@ -869,6 +869,20 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     fill_detect_layout(g);
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
+    // LDS partition of a CU in the batch pipeline (profiles/r04_lds_counters.txt, "LDS request sweep"): the lanes overlap k_detect of one image
+    // group with k_describe of another, and what decides whether a k_describe workgroup can start on a CU that k_detect fills is LDS, which
+    // is handed out in 1280-byte granules.  The request is therefore raised to the largest one that still lets four k_detect workgroups AND
+    // one k_describe workgroup share the 160 KB: (163840 - 30720) / 4 = 33280 B.  One granule more loses k_describe's slot (C2: 119.6 k ->
+    // 116.7 k pairs/s), one less admits a fifth k_detect workgroup that takes it (118.2 k; tile 58: 138.7 k against 146.0 k).
+    {
+        hipFuncAttributes fa{};
+        const size_t cu_lds = 160 * 1024, gran = 1280;
+        if (hipFuncGetAttributes(&fa, describe_kernel_address()) == hipSuccess && !getenv("JSORB_DETECT_LDS_NATURAL")) {
+            const size_t desc = (fa.sharedSizeBytes + gran - 1) / gran * gran;
+            const size_t want = desc < cu_lds ? (cu_lds - desc) / 4 / gran * gran : 0;
+            if (e->detect_lds <= want) e->detect_lds = want;
+        }
+    }
     e->pyr_lds = pyramid_lds_bytes(g);
     for (int i = 1; i < g.L; i++)
         if (g.lv[i].pyr_ns16 > 4) { e->err = "pyramid scale too large for the resampler (level scale must stay below 19)"; return JSORB_ERR_INVALID; }

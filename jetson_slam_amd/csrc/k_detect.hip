@@ -92,11 +92,13 @@ void fill_detect_layout(Geometry &g)
 {
     size_t budget = 0;
     for (int i = 0; i < g.L; i++) budget = std::max(budget, detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok).total);
-    // The allocation may grow to the size that leaves FIVE workgroups per CU if that lets more tile rows share a workgroup: every wave
-    // pays a prologue of ~230 scalar + ~150 vector instructions, and the scalar pipe is nearly as busy as the vector pipes in this kernel.
-    // Measured at the end of round 3 (pairs/s at C2 / C3 / C5): 7 workgroups per CU (the round-2 choice) 107.1 / 80.6 / 30.8 k,
-    // 6: 109.7 / 84.9 / 31.7 k, 5: 111.7 / 85.5 / 32.0-32.3 k, 4: 109.5 / 85.7 / 31.6 k.  The kernel's own duration barely moves; what
-    // the fewer, larger workgroups leave of a CU goes to the kernels of the other lanes.
+    // The allocation may grow to just under a fifth of a CU's LDS if that lets more tile rows share a workgroup: every wave pays a prologue
+    // of ~230 scalar + ~150 vector instructions, and the scalar pipe is nearly as busy as the vector pipes in this kernel.  Measured at the
+    // end of round 3 (pairs/s at C2 / C3 / C5): 7 workgroups per CU (the round-2 choice) 107.1 / 80.6 / 30.8 k, 6: 109.7 / 84.9 / 31.7 k,
+    // 5: 111.7 / 85.5 / 32.0-32.3 k, 4: 109.5 / 85.7 / 31.6 k.  The kernel's own duration barely moves; what the fewer, larger workgroups
+    // leave of a CU goes to the kernels of the other lanes.  Round 4: with the lists' dump slots the layout at this budget lands on 26
+    // LDS granules (33280 B), i.e. FOUR k_detect workgroups per CU plus exactly the 30720 B of one k_describe workgroup - jsorb_create
+    // raises the request to that size on purpose (see there); a larger band budget than this one changes nothing measurable.
     if (const char *b7 = getenv("JSORB_DETECT_BUDGET")) budget = std::max(budget, (size_t)atoi(b7));
     else budget = std::max(budget, (size_t)(160 * 1024 / 5 - 256));
     int dblk = 0;
