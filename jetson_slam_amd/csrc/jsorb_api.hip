@@ -155,6 +155,7 @@ struct jsorb_extractor {
     uint8_t *h_upload = nullptr;
     hipEvent_t ev_upload_read = nullptr;   // recorded right behind k_upload_level0: the pinned buffer may be rewritten once it has fired
     bool upload_inflight = false;
+    bool sync_single = false;              // inside jsorb_extract / jsorb_extract_into: the call itself waits for the frame, nobody needs ev_upload_read (one barrier packet less in front of the match)
     int kernel_upload = 1;
     bool upload_pending = false;       // transient: run_pipeline starts the single-image chain with the upload kernel
     int fg_recaptures = 0;             // consecutive frames whose arguments differed from the captured ones
@@ -622,7 +623,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
                 else {
                     HIPCHK(e, hipGraphLaunch(e->frame_graph, st));
                     HIPCHK(e, hipEventRecord(e->lane_done[j], st));
-                    if (e->upload_pending) { HIPCHK(e, hipEventRecord(e->ev_upload_read, st)); e->upload_inflight = true; }
+                    if (e->upload_pending && !e->sync_single) { HIPCHK(e, hipEventRecord(e->ev_upload_read, st)); e->upload_inflight = true; }
                     continue;
                 }
             }
@@ -681,7 +682,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         }
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->lane_done[j], st));
-        if (e->upload_pending) { HIPCHK(e, hipEventRecord(e->ev_upload_read, st)); e->upload_inflight = true; }      // (recorded behind the frame: an event record inside the captured graph is not an option on this runtime)
+        if (e->upload_pending && !e->sync_single) { HIPCHK(e, hipEventRecord(e->ev_upload_read, st)); e->upload_inflight = true; }      // (recorded behind the frame: an event record inside the captured graph is not an option on this runtime)
     }
     e->copy_kind = 0;
     e->upload_pending = false;
@@ -752,7 +753,7 @@ void spec_after_extract(jsorb_extractor *e, int n)
     if (ok) {
         const StereoArgs sa = make_stereo_args(S->mb, S->mbf, S->th_high, S->th_low);
         launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts, r->desc, r->row_tab,
-                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st);
+                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st, nullptr, DeliverStereo{l->h_sp_u, l->h_sp_d, nullptr});
         launch_median(l->g, l->counts, l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, l->sp_stats, 1, st, DeliverStereo{l->h_sp_u, l->h_sp_d, l->h_sp_stats});
         ok = hipGetLastError() == hipSuccess && hipEventRecord(S->ev_done, st) == hipSuccess;
         // whatever went out on the stream reads both handles' buffers: their next extracts are ordered after it in any case
@@ -1281,7 +1282,10 @@ static int finish_single_frame(jsorb_extractor *e, int *n_keypoints)
 
 int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints)
 {
+    if (!e) return JSORB_ERR_INVALID;
+    e->sync_single = true;
     int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
+    e->sync_single = false;
     if (rc) return rc;
     return finish_single_frame(e, n_keypoints);
 }
@@ -1291,7 +1295,9 @@ int jsorb_extract_into(jsorb_extractor *e, const uint8_t *host_image, int step, 
     if (!e) return JSORB_ERR_INVALID;
     e->deliver_kp_dev = dev_keypoints_dst;
     e->deliver_desc_dev = dev_descriptors_dst;
+    e->sync_single = true;
     int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
+    e->sync_single = false;
     e->deliver_kp_dev = nullptr;
     e->deliver_desc_dev = nullptr;
     if (rc) return rc;
@@ -1497,7 +1503,8 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
                                               l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_stride,
                                               l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st,
-                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr));
+                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr,
+                                              direct ? DeliverStereo{l->h_u, l->h_d, nullptr} : DeliverStereo{nullptr, nullptr, nullptr}));
         TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
                                               l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, l->h_stats + f * 8}));
         HIPCHK(l, hipGetLastError());

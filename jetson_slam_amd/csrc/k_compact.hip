@@ -82,6 +82,10 @@ __device__ __forceinline__ int compact_pos_of(int j, int T, int total, const uns
     return s_base[cell] + __popcll(s_bal[cell] & ((1ull << (j & 63)) - 1ull));
 }
 
+// NC > 0: the image has at most NC chunks of 1024 tiles and a thread keeps its NC candidates in registers over the three passes - one
+// memory round trip for all of them instead of one per chunk and pass, and the bucket scatter at the end works from the registers instead of
+// re-reading the list the workgroup has just written (single frames: 10 -> 6 us of a kernel every other kernel of the frame waits for).
+template <int NC>
 __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigned long long *__restrict__ tile_out,
                                                        unsigned long long *__restrict__ kp, int *__restrict__ counts,
                                                        int *__restrict__ row_tab, int *__restrict__ counts_host)
@@ -106,11 +110,28 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     int *rt = row_tab + (size_t)b * g.row_tab_stride;
     int *tp = rt + g.row_tab_len;                              // per-tile start table: index of the first keypoint at or after tile j (T + 1 entries)
     const int n_chunks = (T + 1023) >> 10, n_cells = n_chunks * 16;
-    for (int c = 0; c < n_chunks; c++) {
-        const int j = c * 1024 + tid;
-        const unsigned long long p = j < T ? tin[j] : 0ull;
-        const unsigned long long bal = __ballot(kp_score(p) > 0);
-        if (lane == 0) s_bal[c * 16 + wave] = bal;
+    constexpr int NR = NC > 0 ? NC : 1;
+    unsigned long long preg[NR];
+    int posr[NR], bktr[NR];
+    if (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NR; c++) {
+            const int j = c * 1024 + tid;
+            preg[c] = j < T ? tin[j] : 0ull;
+        }
+#pragma unroll
+        for (int c = 0; c < NR; c++) {
+            if (c >= n_chunks) break;
+            const unsigned long long bal = __ballot(kp_score(preg[c]) > 0);
+            if (lane == 0) s_bal[c * 16 + wave] = bal;
+        }
+    } else {
+        for (int c = 0; c < n_chunks; c++) {
+            const int j = c * 1024 + tid;
+            const unsigned long long p = j < T ? tin[j] : 0ull;
+            const unsigned long long bal = __ballot(kp_score(p) > 0);
+            if (lane == 0) s_bal[c * 16 + wave] = bal;
+        }
     }
     __syncthreads();
     {   // exclusive prefix over the n_cells <= 1024 cells (one per thread)
@@ -130,16 +151,34 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     }
     __syncthreads();
     const int total = s_total;
-    for (int c = 0; c < n_chunks; c++) {
-        const int j = c * 1024 + tid;
-        if (j >= T) break;
-        const unsigned long long p = tin[j];
-        if (kp_score(p) > 0) {
-            int lvl = 0;
+    if (NC > 0) {
 #pragma unroll
-            for (int i = 1; i < JSORB_MAX_LEVELS; i++) lvl += j >= s_toff[i] ? 1 : 0;
-            kout[compact_pos_of(j, T, total, s_bal, s_base)] = p | ((unsigned long long)lvl << 44);
-            if (EN) atomicAdd(&s_epi[lvl * EH + min((int)((float)kp_y(p) * s_scale[lvl]), EH - 1)], 1);
+        for (int c = 0; c < NR; c++) {
+            const int j = c * 1024 + tid;
+            posr[c] = -1; bktr[c] = 0;
+            if (j < T && kp_score(preg[c]) > 0) {
+                int lvl = 0;
+#pragma unroll
+                for (int i = 1; i < JSORB_MAX_LEVELS; i++) lvl += j >= s_toff[i] ? 1 : 0;
+                preg[c] |= (unsigned long long)lvl << 44;
+                posr[c] = compact_pos_of(j, T, total, s_bal, s_base);
+                kout[posr[c]] = preg[c];
+                bktr[c] = lvl * EH + min((int)((float)kp_y(preg[c]) * s_scale[lvl]), EH - 1);
+                if (EN) atomicAdd(&s_epi[bktr[c]], 1);
+            }
+        }
+    } else {
+        for (int c = 0; c < n_chunks; c++) {
+            const int j = c * 1024 + tid;
+            if (j >= T) break;
+            const unsigned long long p = tin[j];
+            if (kp_score(p) > 0) {
+                int lvl = 0;
+#pragma unroll
+                for (int i = 1; i < JSORB_MAX_LEVELS; i++) lvl += j >= s_toff[i] ? 1 : 0;
+                kout[compact_pos_of(j, T, total, s_bal, s_base)] = p | ((unsigned long long)lvl << 44);
+                if (EN) atomicAdd(&s_epi[lvl * EH + min((int)((float)kp_y(p) * s_scale[lvl]), EH - 1)], 1);
+            }
         }
     }
     // first keypoint at or after every tile (the stereo matcher's column pruning)
@@ -192,6 +231,18 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
     __syncthreads();
     // dense pass over the compacted list this workgroup has just written (level in the record, scale from LDS): four independent
     // records per thread and round, so that their load latencies overlap - the kernel is one workgroup per image and pure latency
+    if (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NR; c++) {
+            if (posr[c] < 0) continue;
+            const int lvl = kp_level(preg[c]);
+            const float sc = s_scale[lvl];
+            const int yi = (int)((float)kp_y(preg[c]) * sc), xi = (int)((float)kp_x(preg[c]) * sc);
+            const int slot = atomicAdd(&s_epi[bktr[c]], 1);
+            ee[slot] = make_int2(posr[c], (xi & 0xFFFF) | (yi << 16));
+        }
+        return;
+    }
     for (int i0 = tid; i0 < total; i0 += 4096) {
         unsigned long long p[4];
 #pragma unroll
@@ -211,8 +262,11 @@ __global__ __launch_bounds__(1024) void k_compact_flat(Geometry g, const unsigne
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s, int *counts_host)
 {
-    if (g.T <= CMP_MAX_CHUNKS * 1024)
-        hipLaunchKernelGGL(k_compact_flat, dim3(n_images), dim3(1024), g.epi_rows ? (size_t)g.L * g.epi_rows * sizeof(int) : 0, s, g, tile_out, kp, counts,
+    if (g.T <= 4 * 1024)
+        hipLaunchKernelGGL(k_compact_flat<4>, dim3(n_images), dim3(1024), g.epi_rows ? (size_t)g.L * g.epi_rows * sizeof(int) : 0, s, g, tile_out, kp, counts,
+                           row_tab, counts_host);
+    else if (g.T <= CMP_MAX_CHUNKS * 1024)
+        hipLaunchKernelGGL(k_compact_flat<0>, dim3(n_images), dim3(1024), g.epi_rows ? (size_t)g.L * g.epi_rows * sizeof(int) : 0, s, g, tile_out, kp, counts,
                            row_tab, counts_host);
     else
         hipLaunchKernelGGL(k_compact, dim3(n_images), dim3(1024), 0, s, g, tile_out, kp, counts, row_tab, counts_host);
