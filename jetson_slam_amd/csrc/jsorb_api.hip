@@ -213,6 +213,7 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
     if (!(p.scale_factor > 1.0f) && p.n_levels > 1) { err = "scale_factor must be > 1"; return JSORB_ERR_INVALID; }
     memset(&g, 0, sizeof(g));
     g.L = p.n_levels;
+    g.latency = p.max_batch <= 1 && !(getenv("JSORB_THROUGHPUT_LAYOUT") && atoi(getenv("JSORB_THROUGHPUT_LAYOUT")) != 0);
     g.threshold = p.th_fast_max;   // th_FAST_MIN is overwritten in the reference (orb_gpu.cpp:42-47)
     float scale[JSORB_MAX_LEVELS], inv[JSORB_MAX_LEVELS];
     scale[0] = 1.0f; inv[0] = 1.0f;

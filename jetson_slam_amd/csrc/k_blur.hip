@@ -77,7 +77,9 @@ void fill_blur_layout(Geometry &g)
         lv.blur_blk0 = bblk;
         if (rw <= 0 || rh <= 0) { lv.blur_bx = 1; lv.blur_by = 0; lv.blur_rb = 1; lv.blur_recip = 0; continue; }
         const int ncs = (rw + BLUR_SW - 1) / BLUR_SW;
-        const int nrb = (rh + BLUR_RB_MAX - 1) / BLUR_RB_MAX;
+        // single-image handles: 8-row bands - twice the workgroups, half as long (k_blur of one EuRoC image 15-17 -> 8-11 us)
+        const int rb_max = getenv("JSORB_BLUR_ROWS") ? std::max(1, std::min(BLUR_RB_MAX, atoi(getenv("JSORB_BLUR_ROWS")))) : (g.latency ? 8 : BLUR_RB_MAX);
+        const int nrb = (rh + rb_max - 1) / rb_max;
         lv.blur_bx = ncs;                                   // strips per band
         lv.blur_by = nrb;                                   // bands
         lv.blur_rb = (rh + nrb - 1) / nrb;                  // rows per band (the last one may be shorter)

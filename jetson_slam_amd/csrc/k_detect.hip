@@ -107,7 +107,7 @@ void fill_detect_layout(Geometry &g)
         int R = 1;
         // only the arg-max form of the tile reduction (tree_rank_ok) handles several tile rows; keys: R * k_tiles <= 128 slots, row index < 256
         while (lv.tree_rank_ok && R < DET_MAX_R && R < lv.nth && (R + 1) * lv.k_tiles <= 128 && (R + 1) * lv.th + 2 <= 255 &&
-               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1).total <= budget && !getenv("JSORB_DETECT_NO_BANDS"))
+               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1).total <= budget && !getenv("JSORB_DETECT_NO_BANDS") && !g.latency)      // single-image handles: one tile row per workgroup
             R++;
         lv.det_R = R;
         lv.detect_blk0 = dblk;

@@ -48,3 +48,15 @@ CONFIGS = {
 @pytest.fixture(scope="session")
 def configs():
     return CONFIGS
+
+
+@pytest.fixture(params=["latency", "throughput"])
+def layout(request, monkeypatch):
+    """Launch layouts of a handle created with max_batch = 1 (the reference's call shape): by default many short workgroups (8-row pyramid strips
+    and blur bands, one tile row per k_detect workgroup: jsorb_create, Geometry::latency); JSORB_THROUGHPUT_LAYOUT=1 gives such a handle the
+    layouts of the batch handles (long strips, bands of tile rows).  Tests that take this fixture run once with each."""
+    if request.param == "throughput":
+        monkeypatch.setenv("JSORB_THROUGHPUT_LAYOUT", "1")
+    else:
+        monkeypatch.delenv("JSORB_THROUGHPUT_LAYOUT", raising=False)
+    return request.param
