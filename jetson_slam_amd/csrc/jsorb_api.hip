@@ -650,12 +650,16 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         } while (0)
         if (e->upload_pending) launch_upload_level0(e->h_upload, e->stage[0], (size_t)g.lv[0].H * g.lv[0].W, st);
         JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
-        JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
+        // single image: k_detect and k_blur (independent of each other) as ONE launch - a frame is a chain of small launches whose latencies add up
+        static const bool fuse_env = !(getenv("JSORB_FUSED_DETECT_BLUR") && atoi(getenv("JSORB_FUSED_DETECT_BLUR")) == 0);
+        const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0;
+        if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
+        else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
         if (e->nms_ms)
             JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
                                                       e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
         JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_stride, m, st, e->h_counts + f * CW));
-        JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
+        if (!fused) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
         JSORB_STAGE(JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st,
                                                       direct ? Deliver{e->deliver_kp_dev, e->deliver_desc_dev, e->h_kp, e->h_desc, nullptr}
                                                              : Deliver{nullptr, nullptr, nullptr, nullptr, nullptr}));

@@ -33,6 +33,8 @@ void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, 
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s, int *counts_host = nullptr);
+void launch_detect_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab, const uint32_t *lut_bits,
+                        unsigned long long *tile_out, uint8_t *blur_slab, size_t lds_bytes, hipStream_t s);      // single image: k_detect and k_blur as one launch
 void fill_blur_layout(Geometry &g);        // k_blur: strips x bands per level, workgroups per level (host side, once per handle)
 int blur_level_blocks(const LevelDesc &lv);
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s);

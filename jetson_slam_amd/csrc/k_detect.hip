@@ -27,6 +27,7 @@
 #include <cstring>
 
 #include "jsorb_launch.h"
+#include "k_blur_body.h"
 
 namespace jsorb {
 
@@ -183,17 +184,14 @@ extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
 #define DET_TACC(k, a, b) do { } while (0)
 #endif
 
+// one workgroup of k_detect: image b, workgroup blk of the image's g.detect_blocks (a kernel of its own for batches, one half of the fused
+// k_detect_blur launch for single frames - both below)
 template <bool HAS_MASK, bool COMPASS, bool SWAR>
-__global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
+__device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
+                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
-    // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
-    // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
-    asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
-    int b, blk;
-    if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
 #ifdef DET_TIMING
     unsigned long long det_t[9] = {};
 #endif
@@ -667,10 +665,47 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src
     }
 }
 
+template <bool HAS_MASK, bool COMPASS, bool SWAR>
+__global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
+                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
+{
+    // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
+    // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
+    asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
+    int b, blk;
+    if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
+    detect_workgroup<HAS_MASK, COMPASS, SWAR>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk);
+}
+
+// Single frames: k_blur does not depend on k_detect (both read the pyramid), and a frame is a chain of small launches whose latencies add up -
+// so the two run as ONE launch: workgroups [0, detect_blocks) are k_detect's, the rest k_blur's (both 256 threads; LDS = k_detect's dynamic
+// part + k_blur's static 10 KB, registers = the larger of the two - irrelevant for one image, which does not fill the chip).  A frame's
+// chain is then upload - pyramid - detect+blur - compact - describe: one launch and k_blur's ~8 us less on the critical path.
+static_assert(DET_THREADS == BLUR_THREADS, "the fused launch runs both kinds of workgroups with one block size");
+template <bool HAS_MASK, bool COMPASS, bool SWAR>
+__global__ __launch_bounds__(DET_THREADS) void k_detect_blur(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
+                                                     const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, uint8_t *blur_slab)
+{
+    const int blk = (int)blockIdx.x;
+    if (blk < g.detect_blocks) detect_workgroup<HAS_MASK, COMPASS, SWAR>(g, src, slab, mask_slab, lut_bits, tile_out, 0, blk);
+    else blur_workgroup(g, src, slab, blur_slab, lut_bits, 0, blk - g.detect_blocks);
+}
+
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
 {
 #define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
+#define DETECT_LAUNCH2(M) do { if (g.det_swar_t4 > 0) DETECT_LAUNCH(M, true, true); else DETECT_LAUNCH(M, true, false); } while (0)
+    if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH2(true); else DETECT_LAUNCH(true, false, false); }
+    else            { if (g.lut_compass) DETECT_LAUNCH2(false); else DETECT_LAUNCH(false, false, false); }
+#undef DETECT_LAUNCH2
+#undef DETECT_LAUNCH
+}
+
+void launch_detect_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab, const uint32_t *lut_bits,
+                        unsigned long long *tile_out, uint8_t *blur_slab, size_t lds_bytes, hipStream_t s)
+{
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect_blur<M, C, S>), dim3(g.detect_blocks + g.blur_blocks), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, blur_slab)
 #define DETECT_LAUNCH2(M) do { if (g.det_swar_t4 > 0) DETECT_LAUNCH(M, true, true); else DETECT_LAUNCH(M, true, false); } while (0)
     if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH2(true); else DETECT_LAUNCH(true, false, false); }
     else            { if (g.lut_compass) DETECT_LAUNCH2(false); else DETECT_LAUNCH(false, false, false); }

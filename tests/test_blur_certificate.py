@@ -16,7 +16,7 @@ U = Fraction(1, 2 ** 24)
 
 
 def _kernel_constants():
-    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur.hip")).read()
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur_body.h")).read()
     delta = float(re.search(r"#define BLUR_BAND ([0-9.e+-]+)f", src).group(1))
     assert delta == 2.0 ** -8 and "const float magic = 49152.0f;" in src         # the band IS the ulp of the magic number
     assert src.index("// horizontal stage") < src.index("// vertical stage")    # stage order of the kernel (round 4): horizontal sums first, vertical sum of those

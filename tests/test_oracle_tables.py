@@ -55,7 +55,7 @@ def test_gauss_weights_definition(po):
     g = (g / s).astype(np.float32)
     assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
     # the HIP kernel embeds the same bit patterns
-    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur.hip")).read()
+    src = open(os.path.join(ROOT, "jetson_slam_amd", "csrc", "k_blur_body.h")).read()
     for b in sorted(set(w.view(np.uint32).tolist())):
         assert ("0x%08X" % b) in src
 

@@ -55,7 +55,7 @@ def kernel_mix(asm_text, names):
     lines = asm_text.split("\n")
     starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
     for i0, sym in starts:
-        name = next((n for n in names if n in sym), None)
+        name = next((n for n in names if "%d%s" % (len(n), n) in sym), None)      # Itanium mangling: <length><name> - k_detect must not match k_detect_blur
         if not name:
             continue
         depth, tot_w, tot_c, n_static, n2 = 0, 0.0, 0.0, 0, 0
