@@ -18,6 +18,9 @@
 // (keypoints of one tile row are contiguous and ordered) remain as the fallback for geometries whose buckets do not fit k_compact's
 // LDS (JSORB_STEREO_EPI=0 forces it).  Candidate order (ascending iR in the reference) only matters for ties, which the
 // (distance << 20 | iR) min-key reproduces.
+#include <algorithm>
+#include <cstdlib>
+
 #include "jsorb_launch.h"
 
 namespace jsorb {
@@ -38,29 +41,41 @@ __device__ __forceinline__ void wave_lds_sync_st()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave64 (= one 64-thread workgroup) handles FOUR left keypoints, 16 lanes each: the per-keypoint scalar work (set-up,
-// scaling/rounding, parabola, depth) is issued once per four keypoints - the path is vector-issue bound.
-//  * candidate phase: the <=3 octave ranges of a keypoint are merged into one flat index space so that consecutive lanes read
-//    consecutive right keypoints (coordinates and 32-byte descriptors: coalesced) and the dependent-load chain is paid once;
-//  * L1 phase: the 11x16 B left window and the 11x32 B right search band of each keypoint are staged in LDS with coalesced
-//    dword loads (the divergent byte gathers of a per-pixel formulation bound the first version: the vector memory pipeline
-//    handled ~1 lane/clk); 121 (row, shift) tasks per keypoint accumulate |(L-Lc)-(R-Rc)| from LDS into 11 LDS counters.
+// Round 4 (second half): ONE wave64 handles up to 32 left keypoints in three phases.
+//  A   candidate search, as before: 16 lanes per left keypoint, four keypoints per pass, `npass` passes (8 for batches; 1 for a single pair,
+//      where the latency of a wave counts, not the number of instructions); the arg-min key and the candidate count of every keypoint go to LDS.
+//  A2  lane = keypoint (32 lanes): everything the reference does once per left keypoint between K12 and K13 - match threshold, scaled
+//      coordinates, the window-fits test - is issued ONCE per 32 keypoints instead of once per pass of four; the keypoints whose window search
+//      runs are ranked by a ballot, their window addresses and the centre pixels of both windows (Lc, Rc_s) are staged in LDS.
+//  B   the L1 sums as a FLAT list of (keypoint, window row) tasks, 64 per pass: a lane owns one row of one keypoint's window and evaluates
+//      all 11 shifts as before; the 11 per-row sums are added into the keypoint's LDS counters two per ds_add_u32 (a window's sum is < 2^16).
+//      Round 3 ran this phase with 11 of every 16 lanes, for unmatched keypoints too: 8 passes per 32 keypoints where 11 * n_refined / 64
+//      (4.4 at the EuRoC shape, 4.9 KAIST-shaped) are needed.
+//  C   lane = keypoint again: arg-min of the 11 sums, parabola, disparity test, depth, and one coalesced store per output array.
+#define ST_MAX_PASS 8
+#define ST_MAX_KP (SKPW * ST_MAX_PASS)
 __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const uint8_t *slabL, ImageSrc srcR, const uint8_t *slabR,
                                                const int32_t *__restrict__ outL, const int *__restrict__ countsL, const uint8_t *__restrict__ descL,
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
                                                const int *__restrict__ row_tabR,
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
-                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag, DeliverStereo dl)
+                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag, DeliverStereo dl, int npass)
 {
     __shared__ int s_lvi[JSORB_MAX_LEVELS][12];      // th, nth, row_tab_off, W, pitch, img_off, 1/th magic, tw, ntw, tile_off, 1/tw magic (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
+    __shared__ unsigned s_best[ST_MAX_KP];           // phase A -> A2: arg-min key of K12 per keypoint slot
+    __shared__ int s_ncand[ST_MAX_KP];
+    __shared__ __align__(16) unsigned s_par[ST_MAX_KP][8];      // per REFINED keypoint (rank): window row 0 of the left / right image (64-bit addresses), the two pitches, the byte shifts
+    __shared__ __align__(16) unsigned s_ctr[ST_MAX_KP][4];      // centre row: W[1] of the left window, X[1..3] of the right band
+    __shared__ __align__(16) unsigned s_acc[ST_MAX_KP][8];      // the 11 L1 sums, two per dword
     const int lane = threadIdx.x;
     const int grp = lane / SGL, sl = lane % SGL;
+    const int kpw = SKPW * npass;                    // left keypoints of this wave
     int b, blk;
-    if (!xcd_map((g.T + SKPW - 1) / SKPW, n_pairs, b, blk)) return;
+    if (!xcd_map((g.T + kpw - 1) / kpw, n_pairs, b, blk)) return;
     const int Nl = uniform_i32(countsL[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
     const int Nr = uniform_i32(countsR[b * (JSORB_MAX_LEVELS + 1) + JSORB_MAX_LEVELS]);
-    if (blk * SKPW >= Nl) return;                     // whole wave idle
+    if (blk * kpw >= Nl) return;                      // whole wave idle
     if (lane < g.L) {
         const LevelDesc &lv = g.lv[lane];
         s_lvi[lane][3] = lv.W; s_lvi[lane][4] = lv.pitch; s_lvi[lane][5] = (int)lv.img_off;
@@ -72,174 +87,192 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         }
         s_lvf[lane][0] = lv.scale; s_lvf[lane][1] = lv.inv_scale;
     }
+    if (lane < ST_MAX_KP) { s_best[lane] = 0xFFFFFFFFu; s_ncand[lane] = 0; }
+    reinterpret_cast<uint4 *>(s_acc)[lane] = make_uint4(0, 0, 0, 0);          // 32 x 8 dwords = 64 x 16 bytes
+    static_assert(ST_MAX_KP * 8 * 4 == 64 * 16, "one 16-byte store per lane clears the L1 counters");
     wave_lds_sync_st();
-    const int i_raw = blk * SKPW + grp;
-    const bool live = i_raw < Nl;
-    const int i = live ? i_raw : Nl - 1;              // idle groups shadow the last keypoint and write nothing
     const int32_t *oL = outL + (size_t)b * 6 * g.T;
     const int32_t *oR = outR + (size_t)b * 6 * g.T;
-    const int xL0 = oL[i], yL0 = oL[Nl + i], levelL = oL[4 * (size_t)Nl + i];
-    const float uL = (float)xL0, vL = (float)yL0;
-    const float minU = uL - sa.maxD, maxU = uL - 0.0f;
     const size_t tb = (size_t)b * g.T;
 
-    unsigned best_key = 0xFFFFFFFFu;
-    int n_cand = 0;
-    {
-        const uint4 *dl = reinterpret_cast<const uint4 *>(descL + (tb + i) * 32);
-        const uint4 a0 = dl[0], a1 = dl[1];
-        const int vLi = (int)vL;
-        const int *rt = row_tabR + (size_t)b * g.row_tab_stride;
-        if (g.epi_rows) {
-            // Scan-line buckets (k_compact): a right keypoint of level lr in row y (its level-0 row, an integer) covers row vL iff
-            // floor(y - r) <= vL <= ceil(y + r), r = 2 * scale[lr], both evaluated in f32 as the reference does.  Both bounds are
-            // non-decreasing in y, so the rows that pass form ONE run [first, last] of that level's buckets: it is found exactly here,
-            // once per level (lane t < 3 of the group takes level levelL - 1 + t and walks in from a bound that is two rows too wide on
-            // each side), and the candidates need no row test of their own.  The three runs are then walked as one flat index space:
-            // 16 entries of 8 bytes per step, coalesced.
-            const int EH = g.epi_rows, EN = g.L * EH;
-            const int *et = rt + g.epi_off;
-            const int2 *ee = reinterpret_cast<const int2 *>(et + ((EN + 2) & ~1));
-            int seg_start = 0, seg_len = 0;
-            {
-                const int lr = levelL - 1 + sl;
-                if (sl < 3 && lr >= 0 && lr < g.L && !(maxU < 0)) {
-                    const float r = 2.0f * s_lvf[lr][0], vLf = (float)vLi;
-                    const float lo_f = __builtin_floorf(vLf - 2.0f - r), hi_f = __builtin_ceilf(vLf + 2.0f + r);
-                    int below = 0, above = 0;                 // rows at the low / high end of [lo, hi] that do not cover vL
+    // ---- phase A: candidate search, four left keypoints per pass ----
+    for (int pass = 0; pass < npass; pass++) {
+        if (blk * kpw + pass * SKPW >= Nl) break;     // (wave-uniform)
+        const int i_raw = blk * kpw + pass * SKPW + grp;
+        const bool live = i_raw < Nl;
+        const int i = live ? i_raw : Nl - 1;          // idle groups shadow the last keypoint and report nothing
+        const int xL0 = oL[i], yL0 = oL[Nl + i], levelL = oL[4 * (size_t)Nl + i];
+        const float uL = (float)xL0, vL = (float)yL0;
+        const float minU = uL - sa.maxD, maxU = uL - 0.0f;
+        (void)yL0;
+        unsigned best_key = 0xFFFFFFFFu;
+        int n_cand = 0;
+        {
+            const uint4 *dl = reinterpret_cast<const uint4 *>(descL + (tb + i) * 32);
+            const uint4 a0 = dl[0], a1 = dl[1];
+            const int vLi = (int)vL;
+            const int *rt = row_tabR + (size_t)b * g.row_tab_stride;
+            if (g.epi_rows) {
+                // Scan-line buckets (k_compact): a right keypoint of level lr in row y (its level-0 row, an integer) covers row vL iff
+                // floor(y - r) <= vL <= ceil(y + r), r = 2 * scale[lr], both evaluated in f32 as the reference does.  Both bounds are
+                // non-decreasing in y, so the rows that pass form ONE run [first, last] of that level's buckets: it is found exactly here,
+                // once per level (lane t < 3 of the group takes level levelL - 1 + t and walks in from a bound that is two rows too wide on
+                // each side), and the candidates need no row test of their own.  The three runs are then walked as one flat index space:
+                // 16 entries of 8 bytes per step, coalesced.
+                const int EH = g.epi_rows, EN = g.L * EH;
+                const int *et = rt + g.epi_off;
+                const int2 *ee = reinterpret_cast<const int2 *>(et + ((EN + 2) & ~1));
+                int seg_start = 0, seg_len = 0;
+                {
+                    const int lr = levelL - 1 + sl;
+                    if (sl < 3 && lr >= 0 && lr < g.L && !(maxU < 0)) {
+                        const float r = 2.0f * s_lvf[lr][0], vLf = (float)vLi;
+                        const float lo_f = __builtin_floorf(vLf - 2.0f - r), hi_f = __builtin_ceilf(vLf + 2.0f + r);
+                        int below = 0, above = 0;                 // rows at the low / high end of [lo, hi] that do not cover vL
 #pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        below += __builtin_ceilf((lo_f + (float)k) + r) < vLf ? 1 : 0;
-                        above += __builtin_floorf((hi_f - (float)k) - r) > vLf ? 1 : 0;
-                    }
-                    const int ylo = max((int)lo_f + below, 0), yhi = min((int)hi_f - above, EH - 1);
-                    if (ylo <= yhi) {
-                        seg_start = et[lr * EH + ylo];
-                        seg_len = et[lr * EH + yhi + 1] - seg_start;
+                        for (int k = 0; k < 5; k++) {
+                            below += __builtin_ceilf((lo_f + (float)k) + r) < vLf ? 1 : 0;
+                            above += __builtin_floorf((hi_f - (float)k) - r) > vLf ? 1 : 0;
+                        }
+                        const int ylo = max((int)lo_f + below, 0), yhi = min((int)hi_f - above, EH - 1);
+                        if (ylo <= yhi) {
+                            seg_start = et[lr * EH + ylo];
+                            seg_len = et[lr * EH + yhi + 1] - seg_start;
+                        }
                     }
                 }
-            }
-            const int gl0 = lane & ~(SGL - 1);
-            const int st0 = __shfl(seg_start, gl0, 64), st1 = __shfl(seg_start, gl0 + 1, 64), st2 = __shfl(seg_start, gl0 + 2, 64);
-            const int c1 = __shfl(seg_len, gl0, 64), c2 = c1 + __shfl(seg_len, gl0 + 1, 64), total = c2 + __shfl(seg_len, gl0 + 2, 64);
-            for (int k = sl; k < total; k += SGL) {
-                const int2 e = ee[(k >= c2 ? st2 - c2 : (k >= c1 ? st1 - c1 : st0)) + k];
-                const float uR = (float)(e.y & 0xFFFF);
-                const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + e.x) * 32);
-                const uint4 b0 = dr[0], b1 = dr[1];
-                if (!(uR >= minU && uR <= maxU)) continue;
-                n_cand++;
-                const int d = hamming256(a0, a1, b0, b1);
-                if (d < sa.th_high) {
-                    const unsigned key = ((unsigned)d << 20) | (unsigned)e.x;
-                    best_key = key < best_key ? key : best_key;
+                const int gl0 = lane & ~(SGL - 1);
+                const int st0 = __shfl(seg_start, gl0, 64), st1 = __shfl(seg_start, gl0 + 1, 64), st2 = __shfl(seg_start, gl0 + 2, 64);
+                const int c1 = __shfl(seg_len, gl0, 64), c2 = c1 + __shfl(seg_len, gl0 + 1, 64), total = c2 + __shfl(seg_len, gl0 + 2, 64);
+                for (int k = sl; k < total; k += SGL) {
+                    const int2 e = ee[(k >= c2 ? st2 - c2 : (k >= c1 ? st1 - c1 : st0)) + k];
+                    const float uR = (float)(e.y & 0xFFFF);
+                    const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + e.x) * 32);
+                    const uint4 b0 = dr[0], b1 = dr[1];
+                    if (!(uR >= minU && uR <= maxU)) continue;
+                    n_cand++;
+                    const int d = hamming256(a0, a1, b0, b1);
+                    if (d < sa.th_high) {
+                        const unsigned key = ((unsigned)d << 20) | (unsigned)e.x;
+                        best_key = key < best_key ? key : best_key;
+                    }
                 }
-            }
-        } else {
-        int j0[3], len[3];
-        int nrw[3], tl0[3], tst[3], ncl[3];      // column-pruned form: tile rows of the band, tile index of (first row, first column), tiles per row, columns of the window
-        float rr[3];
+            } else {
+            int j0[3], len[3];
+            int nrw[3], tl0[3], tst[3], ncl[3];      // column-pruned form: tile rows of the band, tile index of (first row, first column), tiles per row, columns of the window
+            float rr[3];
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int lr = levelL - 1 + t;
-            j0[t] = 0; len[t] = 0; rr[t] = 0.f;
-            nrw[t] = 0; tl0[t] = 0; tst[t] = 0; ncl[t] = 0;
-            if (lr >= 0 && lr < g.L && !(maxU < 0)) {
-                const float scl = s_lvf[lr][0], iscl = s_lvf[lr][1];
-                const int th = s_lvi[lr][0], nth = s_lvi[lr][1], rto = s_lvi[lr][2];
-                const unsigned th_magic = (unsigned)s_lvi[lr][6];
-                const float r = 2.0f * scl;
-                rr[t] = r;
-                // conservative tile-row window of level lr (exact tests follow per candidate): the product with 1/scale instead of
-                // the quotient moves the bounds by ~1e-4 px, the window carries a margin of a whole pixel on each side
-                const int lo = (int)__builtin_floorf((vL - r - 1.0f) * iscl) - 1;
-                const int hi = (int)__builtin_ceilf((vL + r + 2.0f) * iscl) + 1;
-                const int t_lo = lo < 0 ? 0 : (th > 1 ? (int)__umulhi((unsigned)lo, th_magic) : lo);
-                int t_hi = hi < 0 ? -1 : (th > 1 ? (int)__umulhi((unsigned)hi, th_magic) : hi);
-                if (t_hi > nth - 1) t_hi = nth - 1;
-                if (t_lo <= t_hi) {
-                    if (!g.stereo_colprune) {
-                        j0[t] = rt[rto + t_lo];
-                        len[t] = rt[rto + t_hi + 1] - j0[t];
-                    } else {
-                        const int tw = s_lvi[lr][7], ntw = s_lvi[lr][8];
-                        const unsigned tw_magic = (unsigned)s_lvi[lr][10];
-                        const int xlo = (int)__builtin_floorf((minU - 1.0f) * iscl) - 1, xhi = (int)__builtin_ceilf((maxU + 1.0f) * iscl) + 1;
-                        const int c_lo = xlo < 0 ? 0 : (tw > 1 ? (int)__umulhi((unsigned)xlo, tw_magic) : xlo);
-                        int c_hi = xhi < 0 ? -1 : (tw > 1 ? (int)__umulhi((unsigned)xhi, tw_magic) : xhi);
-                        if (c_hi > ntw - 1) c_hi = ntw - 1;
-                        if (c_lo <= c_hi) {
-                            nrw[t] = t_hi - t_lo + 1;
-                            tl0[t] = s_lvi[lr][9] + t_lo * ntw + c_lo;
-                            tst[t] = ntw;
-                            ncl[t] = c_hi - c_lo + 1;
+            for (int t = 0; t < 3; t++) {
+                const int lr = levelL - 1 + t;
+                j0[t] = 0; len[t] = 0; rr[t] = 0.f;
+                nrw[t] = 0; tl0[t] = 0; tst[t] = 0; ncl[t] = 0;
+                if (lr >= 0 && lr < g.L && !(maxU < 0)) {
+                    const float scl = s_lvf[lr][0], iscl = s_lvf[lr][1];
+                    const int th = s_lvi[lr][0], nth = s_lvi[lr][1], rto = s_lvi[lr][2];
+                    const unsigned th_magic = (unsigned)s_lvi[lr][6];
+                    const float r = 2.0f * scl;
+                    rr[t] = r;
+                    // conservative tile-row window of level lr (exact tests follow per candidate): the product with 1/scale instead of
+                    // the quotient moves the bounds by ~1e-4 px, the window carries a margin of a whole pixel on each side
+                    const int lo = (int)__builtin_floorf((vL - r - 1.0f) * iscl) - 1;
+                    const int hi = (int)__builtin_ceilf((vL + r + 2.0f) * iscl) + 1;
+                    const int t_lo = lo < 0 ? 0 : (th > 1 ? (int)__umulhi((unsigned)lo, th_magic) : lo);
+                    int t_hi = hi < 0 ? -1 : (th > 1 ? (int)__umulhi((unsigned)hi, th_magic) : hi);
+                    if (t_hi > nth - 1) t_hi = nth - 1;
+                    if (t_lo <= t_hi) {
+                        if (!g.stereo_colprune) {
+                            j0[t] = rt[rto + t_lo];
+                            len[t] = rt[rto + t_hi + 1] - j0[t];
+                        } else {
+                            const int tw = s_lvi[lr][7], ntw = s_lvi[lr][8];
+                            const unsigned tw_magic = (unsigned)s_lvi[lr][10];
+                            const int xlo = (int)__builtin_floorf((minU - 1.0f) * iscl) - 1, xhi = (int)__builtin_ceilf((maxU + 1.0f) * iscl) + 1;
+                            const int c_lo = xlo < 0 ? 0 : (tw > 1 ? (int)__umulhi((unsigned)xlo, tw_magic) : xlo);
+                            int c_hi = xhi < 0 ? -1 : (tw > 1 ? (int)__umulhi((unsigned)xhi, tw_magic) : xhi);
+                            if (c_hi > ntw - 1) c_hi = ntw - 1;
+                            if (c_lo <= c_hi) {
+                                nrw[t] = t_hi - t_lo + 1;
+                                tl0[t] = s_lvi[lr][9] + t_lo * ntw + c_lo;
+                                tst[t] = ntw;
+                                ncl[t] = c_hi - c_lo + 1;
+                            }
                         }
                     }
                 }
             }
-        }
-        // one right keypoint against this left keypoint: the reference's exact row / column tests, then the Hamming distance
-        auto candidate_at = [&](int j, float kpY, float uR, float r) {
-            const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + j) * 32);
-            const uint4 b0 = dr[0], b1 = dr[1];
-            const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
-            if (vLi < minr || vLi > maxr) return;
-            if (!(uR >= minU && uR <= maxU)) return;
-            n_cand++;
-            const int d = hamming256(a0, a1, b0, b1);
-            if (d < sa.th_high) {
-                const unsigned key = ((unsigned)d << 20) | (unsigned)j;
-                best_key = key < best_key ? key : best_key;
-            }
-        };
-        auto candidate = [&](int j, float r) { candidate_at(j, (float)oR[Nr + j], (float)oR[j], r); };
-        if (!g.stereo_colprune) {
-            const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
-            for (int k = sl; k < total; k += SGL) {
-                const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
-                const int j = (t == 2 ? j0[2] - c2 : (t == 1 ? j0[1] - c1 : j0[0])) + k;
-                candidate(j, t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]));
-            }
-        } else {
-            // Column pruning: the keypoints of a tile row are ordered by tile column (one per tile at most), so those inside the disparity
-            // window [uL - maxD, uL] sit in a contiguous run of tiles.  Every (level, tile row) of the band becomes a SEGMENT
-            // [tile_pos[row, c_lo], tile_pos[row, c_hi + 1]) of the right image's keypoint list (per-tile start table of k_compact); lane s of
-            // the group fetches segment s (one round trip for all of them), then the group walks the segments.  At 64 tiles per row and a
-            // window of 23 tiles this scans a third of what the whole-row form scans.  The window is conservative by a pixel on each side
-            // (a keypoint's level-0 x is int(x_level * scale)); the exact tests above decide.
-            const int *tp = rt + g.row_tab_len;
-            const int c1 = nrw[0], c2 = nrw[0] + nrw[1], nseg = c2 + nrw[2];
-            int nseg_max = nseg;                         // largest segment count of the wave's four keypoints (wave-uniform)
-            nseg_max = max(max(__builtin_amdgcn_readlane(nseg, 0), __builtin_amdgcn_readlane(nseg, 16)),
-                           max(__builtin_amdgcn_readlane(nseg, 32), __builtin_amdgcn_readlane(nseg, 48)));
-            for (int s0 = 0; s0 < nseg_max; s0 += SGL) {
-                const int sg = s0 + sl;
-                int seg_start = 0, seg_len = 0;
-                float seg_r = 0.f;
-                if (sg < nseg) {
-                    const int t = sg >= c2 ? 2 : (sg >= c1 ? 1 : 0);
-                    const int row = sg - (t == 2 ? c2 : (t == 1 ? c1 : 0));
-                    const int tile = (t == 2 ? tl0[2] : (t == 1 ? tl0[1] : tl0[0])) + row * (t == 2 ? tst[2] : (t == 1 ? tst[1] : tst[0]));
-                    seg_start = tp[tile];
-                    seg_len = tp[tile + (t == 2 ? ncl[2] : (t == 1 ? ncl[1] : ncl[0]))] - seg_start;
-                    seg_r = t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]);
+            // one right keypoint against this left keypoint: the reference's exact row / column tests, then the Hamming distance
+            auto candidate_at = [&](int j, float kpY, float uR, float r) {
+                const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + j) * 32);
+                const uint4 b0 = dr[0], b1 = dr[1];
+                const int maxr = (int)__builtin_ceilf(kpY + r), minr = (int)__builtin_floorf(kpY - r);
+                if (vLi < minr || vLi > maxr) return;
+                if (!(uR >= minU && uR <= maxU)) return;
+                n_cand++;
+                const int d = hamming256(a0, a1, b0, b1);
+                if (d < sa.th_high) {
+                    const unsigned key = ((unsigned)d << 20) | (unsigned)j;
+                    best_key = key < best_key ? key : best_key;
                 }
-                const int n_here = min(SGL, nseg_max - s0);
-                for (int q = 0; q < n_here; q++) {
-                    const int src_lane = (lane & ~(SGL - 1)) + q;
-                    const int st = __shfl(seg_start, src_lane, 64), ln = __shfl(seg_len, src_lane, 64);
-                    const float r = __shfl(seg_r, src_lane, 64);
-                    for (int k = sl; k < ln; k += SGL) candidate(st + k, r);
+            };
+            auto candidate = [&](int j, float r) { candidate_at(j, (float)oR[Nr + j], (float)oR[j], r); };
+            if (!g.stereo_colprune) {
+                const int c1 = len[0], c2 = len[0] + len[1], total = c2 + len[2];
+                for (int k = sl; k < total; k += SGL) {
+                    const int t = k >= c2 ? 2 : (k >= c1 ? 1 : 0);
+                    const int j = (t == 2 ? j0[2] - c2 : (t == 1 ? j0[1] - c1 : j0[0])) + k;
+                    candidate(j, t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]));
+                }
+            } else {
+                // Column pruning: the keypoints of a tile row are ordered by tile column (one per tile at most), so those inside the disparity
+                // window [uL - maxD, uL] sit in a contiguous run of tiles.  Every (level, tile row) of the band becomes a SEGMENT
+                // [tile_pos[row, c_lo], tile_pos[row, c_hi + 1]) of the right image's keypoint list (per-tile start table of k_compact); lane s of
+                // the group fetches segment s (one round trip for all of them), then the group walks the segments.  At 64 tiles per row and a
+                // window of 23 tiles this scans a third of what the whole-row form scans.  The window is conservative by a pixel on each side
+                // (a keypoint's level-0 x is int(x_level * scale)); the exact tests above decide.
+                const int *tp = rt + g.row_tab_len;
+                const int c1 = nrw[0], c2 = nrw[0] + nrw[1], nseg = c2 + nrw[2];
+                int nseg_max = nseg;                         // largest segment count of the wave's four keypoints (wave-uniform)
+                nseg_max = max(max(__builtin_amdgcn_readlane(nseg, 0), __builtin_amdgcn_readlane(nseg, 16)),
+                               max(__builtin_amdgcn_readlane(nseg, 32), __builtin_amdgcn_readlane(nseg, 48)));
+                for (int s0 = 0; s0 < nseg_max; s0 += SGL) {
+                    const int sg = s0 + sl;
+                    int seg_start = 0, seg_len = 0;
+                    float seg_r = 0.f;
+                    if (sg < nseg) {
+                        const int t = sg >= c2 ? 2 : (sg >= c1 ? 1 : 0);
+                        const int row = sg - (t == 2 ? c2 : (t == 1 ? c1 : 0));
+                        const int tile = (t == 2 ? tl0[2] : (t == 1 ? tl0[1] : tl0[0])) + row * (t == 2 ? tst[2] : (t == 1 ? tst[1] : tst[0]));
+                        seg_start = tp[tile];
+                        seg_len = tp[tile + (t == 2 ? ncl[2] : (t == 1 ? ncl[1] : ncl[0]))] - seg_start;
+                        seg_r = t == 2 ? rr[2] : (t == 1 ? rr[1] : rr[0]);
+                    }
+                    const int n_here = min(SGL, nseg_max - s0);
+                    for (int q = 0; q < n_here; q++) {
+                        const int src_lane = (lane & ~(SGL - 1)) + q;
+                        const int st = __shfl(seg_start, src_lane, 64), ln = __shfl(seg_len, src_lane, 64);
+                        const float r = __shfl(seg_r, src_lane, 64);
+                        for (int k = sl; k < ln; k += SGL) candidate(st + k, r);
+                    }
                 }
             }
+            }
         }
-        }
+        static_assert(SGL == 16, "the lane group of a keypoint is one DPP row");
+        best_key = row16_min_u32(best_key);           // reduce inside the keypoint's lane group
+        n_cand = row16_sum_i32(n_cand);
+        if (live && sl == 0) { s_best[pass * SKPW + grp] = best_key; s_ncand[pass * SKPW + grp] = n_cand; }
     }
-    static_assert(SGL == 16, "the lane group of a keypoint is one DPP row");
-    best_key = row16_min_u32(best_key);               // reduce inside the keypoint's lane group
-    n_cand = row16_sum_i32(n_cand);
+    wave_lds_sync_st();
 
-    // ---- sub-pixel refinement of the best match (all lanes of the group hold the same values) ----
+    // ---- phase A2: lane = keypoint slot (lanes 32..63 mirror 0..31 and stay passive) ----
+    const int slot = lane & (ST_MAX_KP - 1);
+    const int i_raw = blk * kpw + slot;
+    const bool live = lane < ST_MAX_KP && slot < kpw && i_raw < Nl;
+    const int i = min(i_raw, Nl - 1);
+    const unsigned best_key = s_best[slot];
+    const int n_cand = s_ncand[slot];
+    const int xL0 = oL[i], yL0 = oL[Nl + i], levelL = oL[4 * (size_t)Nl + i];
+    const float uL = (float)xL0, vL = (float)yL0;
     float out_u = -1.0f, out_d = -1.0f;
     int out_l1 = -1, corr = 0;
     const bool matched = best_key != 0xFFFFFFFFu && (int)(best_key >> 20) < sa.th_orb;
@@ -251,11 +284,15 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
     const float scaleduL0 = roundf(uL * iscL);
     const float scaledvL0 = roundf(vL * iscL);
     const float iniu = scaleduR0 - 5.0f - 5.0f, endu = scaleduR0 + 5.0f + 5.0f;
-    const bool refine = matched && !(iniu < 0 || endu >= (float)WL);
-    int pl = 0, pr = 0;
-    const uint8_t *imL = nullptr, *imR = nullptr;
+    const bool refine = live && matched && !(iniu < 0 || endu >= (float)WL);
+    const unsigned long long ref_mask = __ballot(refine);
+    const int n_ref = __popcll(ref_mask);
+    const int rank = __popcll(ref_mask & ((1ull << lane) - 1ull));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4), aligned(4)));
     if (refine) {
         corr = 1;
+        int pl, pr;
+        const uint8_t *imL, *imR;
         if (levelL == 0) {
             pl = srcL.l0_pitch; imL = srcL.l0 + (size_t)b * srcL.l0_stride;
             pr = srcR.l0_pitch; imR = srcR.l0 + (size_t)b * srcR.l0_stride;
@@ -264,29 +301,44 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             imL = slabL + (size_t)b * g.slab_bytes + (unsigned)s_lvi[levelL][5];
             imR = slabR + (size_t)b * g.slab_bytes + (unsigned)s_lvi[levelL][5];
         }
-    }
-    // L1(s) = sum over the 11x11 window of |(L - Lc) - (R_s - Rc_s)| for the 11 shifts s.  Lane r < 11 of the keypoint's lane
-    // group owns window row r: it loads the 16 B (left) / 32 B (right) that cover its row straight from the image (dword
-    // aligned addresses, never past row y+5 <= H-16), byte-aligns them with v_alignbyte and evaluates all 11 shifts with packed
-    // 16-bit SADs: |L - (R + k_s)| with k_s = Lc - Rc_s, both sides biased by 256 so that they stay positive.  The per-row
-    // partial sums are added across the group with DPP row rotations.  No LDS: a misaligned LDS read (any access that is not
-    // naturally aligned, e.g. ds_read_b64 at a byte address) costs 64 clk per wave-instruction on gfx950 - the first version
-    // of this phase spent most of its time there.
-    int acc[11];
-#pragma unroll
-    for (int q = 0; q < 11; q++) acc[q] = 0;
-    {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-        const bool mine = refine && sl < 11;
+        // the 11x16 B (left) / 11x32 B (right) that cover the window rows are read straight from the image (dword aligned addresses,
+        // never past row y+5 <= H-16) and byte-aligned with v_alignbyte.  No LDS staging of pixels: a misaligned LDS read costs 64 clk
+        // per wave-instruction on gfx950 - the first version of this phase spent most of its time there.
         const int xl = (int)scaleduL0, xr = (int)scaleduR0, y = (int)scaledvL0;
         const int la = (xl - 5) & ~3, ra = (xr - 10) & ~3;      // dword aligned window starts
         const unsigned shl = (unsigned)(xl - 5 - la), shr = (unsigned)(xr - 10 - ra);
+        const uint8_t *aL = imL + (size_t)(y - 5) * pl + la, *aR = imR + (size_t)(y - 5) * pr + ra;
+        const u32x4 Lq = *reinterpret_cast<const u32x4 *>(aL + (size_t)5 * pl);
+        const u32x4 Rq0 = *reinterpret_cast<const u32x4 *>(aR + (size_t)5 * pr);
+        const u32x4 Rq1 = *reinterpret_cast<const u32x4 *>(aR + (size_t)5 * pr + 16);
+        const unsigned long long uaL = (unsigned long long)(uintptr_t)aL, uaR = (unsigned long long)(uintptr_t)aR;
+        reinterpret_cast<uint4 *>(s_par[rank])[0] = make_uint4((unsigned)uaL, (unsigned)(uaL >> 32), (unsigned)uaR, (unsigned)(uaR >> 32));
+        reinterpret_cast<uint4 *>(s_par[rank])[1] = make_uint4((unsigned)pl, (unsigned)pr, shl, shr);
+        reinterpret_cast<uint4 *>(s_ctr[rank])[0] = make_uint4(__builtin_amdgcn_alignbyte(Lq.z, Lq.y, shl), __builtin_amdgcn_alignbyte(Rq0.z, Rq0.y, shr),
+                                                               __builtin_amdgcn_alignbyte(Rq0.w, Rq0.z, shr), __builtin_amdgcn_alignbyte(Rq1.x, Rq0.w, shr));
+    }
+    wave_lds_sync_st();
+
+    // ---- phase B: L1(s) = sum over the 11x11 window of |(L - Lc) - (R_s - Rc_s)| for the 11 shifts s, as (keypoint, row) tasks ----
+    // A lane owns one window row: all 11 shifts with packed 16-bit SADs, |L - (R + k_s)| with k_s = Lc - Rc_s, both sides biased by 256
+    // so that they stay positive.
+    const int n_tasks = 11 * n_ref;
+    for (int t0 = 0; t0 < n_tasks; t0 += 64) {
+        const int t = t0 + lane;
+        const bool mine = t < n_tasks;
+        const int tt = mine ? t : 0;
+        const int ridx = (tt * 745) >> 13;            // tt / 11 for tt < 2700
+        const int row = tt - 11 * ridx;
+        const uint4 p0 = reinterpret_cast<const uint4 *>(s_par[ridx])[0], p1 = reinterpret_cast<const uint4 *>(s_par[ridx])[1];
+        const uint4 ctr = reinterpret_cast<const uint4 *>(s_ctr[ridx])[0];
+        const uint8_t *rowL = reinterpret_cast<const uint8_t *>((uintptr_t)(((unsigned long long)p0.y << 32) | p0.x)) + (size_t)row * (int)p1.x;
+        const uint8_t *rowR = reinterpret_cast<const uint8_t *>((uintptr_t)(((unsigned long long)p0.w << 32) | p0.z)) + (size_t)row * (int)p1.y;
+        const unsigned shl = p1.z, shr = p1.w;
         u32x4 Lq = (u32x4){0, 0, 0, 0}, Rq0 = Lq, Rq1 = Lq;
         if (mine) {
-            const size_t row = (size_t)(y - 5 + sl);
-            Lq = *reinterpret_cast<const u32x4 *>(imL + row * pl + la);
-            Rq0 = *reinterpret_cast<const u32x4 *>(imR + row * pr + ra);
-            Rq1 = *reinterpret_cast<const u32x4 *>(imR + row * pr + ra + 16);
+            Lq = *reinterpret_cast<const u32x4 *>(rowL);
+            Rq0 = *reinterpret_cast<const u32x4 *>(rowR);
+            Rq1 = *reinterpret_cast<const u32x4 *>(rowR + 16);
         }
         // window bytes 0..10 of the row in W[0..2]; search band bytes 0..20 in X[0..5]
         unsigned W[3], X[6];
@@ -295,11 +347,8 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         X[0] = __builtin_amdgcn_alignbyte(Rq0.y, Rq0.x, shr); X[1] = __builtin_amdgcn_alignbyte(Rq0.z, Rq0.y, shr);
         X[2] = __builtin_amdgcn_alignbyte(Rq0.w, Rq0.z, shr); X[3] = __builtin_amdgcn_alignbyte(Rq1.x, Rq0.w, shr);
         X[4] = __builtin_amdgcn_alignbyte(Rq1.y, Rq1.x, shr); X[5] = __builtin_amdgcn_alignbyte(Rq1.z, Rq1.y, shr);
-        // centre row (window row 5) of both images: Lc = byte 5 of its W, Rc_s = byte 5+s of its X
-        const int c_lane = (lane & ~(SGL - 1)) + 5;
-        const unsigned cW1 = (unsigned)__shfl((int)W[1], c_lane, 64);
-        const unsigned cX1 = (unsigned)__shfl((int)X[1], c_lane, 64), cX2 = (unsigned)__shfl((int)X[2], c_lane, 64),
-                       cX3 = (unsigned)__shfl((int)X[3], c_lane, 64);
+        // centre row (window row 5) of both images: Lc = byte 5 of its W, Rc_s = byte 5+s of its X - staged per keypoint in phase A2
+        const unsigned cW1 = ctr.x, cX1 = ctr.y, cX2 = ctr.z, cX3 = ctr.w;
         const unsigned cX[4] = {0u, cX1, cX2, cX3};
         const int lc = (int)((cW1 >> 8) & 0xFFu);
         // 16-bit pairs: A[m] = (L[2m], L[2m+1]) + 256 ; E[m] = (R[2m], R[2m+1]) ; O[m] = (R[2m+1], R[2m+2])
@@ -331,18 +380,21 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             }
             part[q] = pq_;
         }
-        // the 11 per-row sums are added across the group TWO shifts at a time: a row's partial sum is < 11 * 510 and a window's sum
-        // <= 121 * 510 = 61710 < 2^16, so two of them share a dword and one DPP reduction (round 4: 24 instead of 44 reduction steps per keypoint)
+        // a row's partial sum is < 11 * 510 and a window's sum <= 121 * 510 = 61710 < 2^16: two shifts share a dword and an LDS addition
+        if (mine) {
 #pragma unroll
-        for (int q2 = 0; q2 < 6; q2++) {
-            unsigned v = mine ? (part[2 * q2] | (part[2 * q2 + 1] << 16)) : 0u;
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);   // row_ror:2
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);   // row_ror:1 -> every lane of the group holds both sums
-            acc[2 * q2] = (int)(v & 0xFFFFu);
-            if (2 * q2 + 1 < 11) acc[2 * q2 + 1] = (int)(v >> 16);
+            for (int q2 = 0; q2 < 6; q2++) atomicAdd(&s_acc[ridx][q2], part[2 * q2] | (part[2 * q2 + 1] << 16));
         }
+    }
+    wave_lds_sync_st();
+
+    // ---- phase C: lane = keypoint slot again ----
+    int acc[11];
+    {
+        const uint4 a0 = reinterpret_cast<const uint4 *>(s_acc[refine ? rank : 0])[0], a1 = reinterpret_cast<const uint4 *>(s_acc[refine ? rank : 0])[1];
+        acc[0] = (int)(a0.x & 0xFFFFu); acc[1] = (int)(a0.x >> 16); acc[2] = (int)(a0.y & 0xFFFFu); acc[3] = (int)(a0.y >> 16);
+        acc[4] = (int)(a0.z & 0xFFFFu); acc[5] = (int)(a0.z >> 16); acc[6] = (int)(a0.w & 0xFFFFu); acc[7] = (int)(a0.w >> 16);
+        acc[8] = (int)(a1.x & 0xFFFFu); acc[9] = (int)(a1.x >> 16); acc[10] = (int)(a1.y & 0xFFFFu);
     }
     if (refine) {
         // first minimum of the 11 sums (strict < in ascending order, :491-505) = minimum of the keys (sum << 4 | shift); sums are < 2^16
@@ -371,7 +423,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
             }
         }
     }
-    if (live && sl == 0) {
+    if (live) {
         u_right[tb + i] = out_u;
         depth[tb + i] = out_d;
         best_l1[tb + i] = out_l1;
@@ -394,6 +446,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         }
     }
 }
+
 
 // 2.1 x median cut (orb_stereo_match.cu:563-578).  The median of the sorted (dist, idx) pairs is the (nv/2)-th smallest
 // distance; L1 distances are < 2^16 (121*510), so a two-pass 256-bin radix select in LDS finds it exactly.
@@ -584,8 +637,19 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
                    float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag, DeliverStereo dl)
 {
-    hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + SKPW - 1) / SKPW, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
-                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, dl);
+    // Passes of four left keypoints per wave.  More passes = fewer instructions per keypoint (phases A2 and C once per wave, fuller task lists in
+    // phase B), but a wave runs its passes one after the other and each pass is a chain of dependent loads: the launch must still consist of
+    // many more waves than the chip holds.  8 passes if that leaves >= 24 k waves (KAIST-shaped batches), else 4, 2, 1; a single pair 1 - a
+    // frame waits for this kernel.  Measured (k_stereo per step, 8 / 6 / 4 / 3 / 2 passes): C2 113 / 113 / 113 / 113 / 123 us, C3 105 / 98 / 97 / 93 / 101 us,
+    // C5 359 / 354 / 364 / 367 / 393 us; round 3 (one pass of four keypoints per wave, refinement in 11 of 16 lanes): 123 / 99 / 398 us.
+    static const int env_pass = getenv("JSORB_STEREO_PASSES") ? std::max(1, std::min(ST_MAX_PASS, atoi(getenv("JSORB_STEREO_PASSES")))) : 0;
+    int npass = 1;
+    if (env_pass) npass = env_pass;
+    else if (n_pairs > 1)
+        for (npass = ST_MAX_PASS; npass > 1 && (long)n_pairs * ((g.T + SKPW * npass - 1) / (SKPW * npass)) < 24576; npass >>= 1) { }
+    const int kpw = SKPW * npass;
+    hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + kpw - 1) / kpw, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
+                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, dl, npass);
 }
 
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
