@@ -144,17 +144,40 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                 const int gl0 = lane & ~(SGL - 1);
                 const int st0 = __shfl(seg_start, gl0, 64), st1 = __shfl(seg_start, gl0 + 1, 64), st2 = __shfl(seg_start, gl0 + 2, 64);
                 const int c1 = __shfl(seg_len, gl0, 64), c2 = c1 + __shfl(seg_len, gl0 + 1, 64), total = c2 + __shfl(seg_len, gl0 + 2, 64);
-                for (int k = sl; k < total; k += SGL) {
-                    const int2 e = ee[(k >= c2 ? st2 - c2 : (k >= c1 ? st1 - c1 : st0)) + k];
-                    const float uR = (float)(e.y & 0xFFFF);
-                    const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + e.x) * 32);
-                    const uint4 b0 = dr[0], b1 = dr[1];
-                    if (!(uR >= minU && uR <= maxU)) continue;
-                    n_cand++;
-                    const int d = hamming256(a0, a1, b0, b1);
-                    if (d < sa.th_high) {
-                        const unsigned key = ((unsigned)d << 20) | (unsigned)e.x;
-                        best_key = key < best_key ? key : best_key;
+                // The kernel waits on its dependent loads (entry -> descriptor), not on its ALUs: three steps of 16 entries are requested
+                // together, the disparity-window test runs on the entries alone, and the three descriptor loads go out together as well
+                // (lanes whose entry fails the test read descriptor 0: one cache line for all of them) - two round trips per 48
+                // candidates instead of six.
+#ifndef ST_CAND_UNROLL
+#define ST_CAND_UNROLL 3
+#endif
+                constexpr int CU = ST_CAND_UNROLL;
+                for (int k = sl; k < total; k += CU * SGL) {
+                    int2 e[CU];
+                    bool ok[CU];
+#pragma unroll
+                    for (int u = 0; u < CU; u++) {
+                        const int kk = k + u * SGL;
+                        const int kc = kk < total ? kk : k;
+                        e[u] = ee[(kc >= c2 ? st2 - c2 : (kc >= c1 ? st1 - c1 : st0)) + kc];
+                    }
+                    uint4 b0[CU], b1[CU];
+#pragma unroll
+                    for (int u = 0; u < CU; u++) {
+                        const float uR = (float)(e[u].y & 0xFFFF);
+                        ok[u] = k + u * SGL < total && uR >= minU && uR <= maxU;
+                        const uint4 *dr = reinterpret_cast<const uint4 *>(descR + (tb + (ok[u] ? e[u].x : 0)) * 32);
+                        b0[u] = dr[0]; b1[u] = dr[1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CU; u++) {
+                        if (!ok[u]) continue;
+                        n_cand++;
+                        const int d = hamming256(a0, a1, b0[u], b1[u]);
+                        if (d < sa.th_high) {
+                            const unsigned key = ((unsigned)d << 20) | (unsigned)e[u].x;
+                            best_key = key < best_key ? key : best_key;
+                        }
                     }
                 }
             } else {
@@ -639,14 +662,15 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
 {
     // Passes of four left keypoints per wave.  More passes = fewer instructions per keypoint (phases A2 and C once per wave, fuller task lists in
     // phase B), but a wave runs its passes one after the other and each pass is a chain of dependent loads: the launch must still consist of
-    // many more waves than the chip holds.  8 passes if that leaves >= 24 k waves (KAIST-shaped batches), else 4, 2, 1; a single pair 1 - a
-    // frame waits for this kernel.  Measured (k_stereo per step, 8 / 6 / 4 / 3 / 2 passes): C2 113 / 113 / 113 / 113 / 123 us, C3 105 / 98 / 97 / 93 / 101 us,
-    // C5 359 / 354 / 364 / 367 / 393 us; round 3 (one pass of four keypoints per wave, refinement in 11 of 16 lanes): 123 / 99 / 398 us.
+    // many more waves than the chip holds.  8 passes if that leaves >= 24 k waves (KAIST-shaped batches), else 6 / 4 / 2 with >= 12 k waves;
+    // a single pair 1 - a frame waits for this kernel.  Measured, pairs/s of the whole pipeline on one box with 8 / 6 / 4 / 2 passes:
+    // C2 123.7 / 123.7 / 122.5 / 121.7 k (round-4 kernel before this one: 121.0 k); k_stereo alone per step C2 101 / 103 / 102 / 112 us,
+    // C3 (before the batched candidate loads) 105 / 98 / 97 / 101 us, C5 359 / 354 / 364 / 393 us.
     static const int env_pass = getenv("JSORB_STEREO_PASSES") ? std::max(1, std::min(ST_MAX_PASS, atoi(getenv("JSORB_STEREO_PASSES")))) : 0;
+    auto waves = [&](int np) { return (long)n_pairs * ((g.T + SKPW * np - 1) / (SKPW * np)); };
     int npass = 1;
     if (env_pass) npass = env_pass;
-    else if (n_pairs > 1)
-        for (npass = ST_MAX_PASS; npass > 1 && (long)n_pairs * ((g.T + SKPW * npass - 1) / (SKPW * npass)) < 24576; npass >>= 1) { }
+    else if (n_pairs > 1) npass = waves(8) >= 24576 ? 8 : waves(6) >= 12288 ? 6 : waves(4) >= 12288 ? 4 : waves(2) >= 12288 ? 2 : 1;
     const int kpw = SKPW * npass;
     hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + kpw - 1) / kpw, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
                        outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, dl, npass);
