@@ -96,20 +96,37 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
     const size_t tb = (size_t)b * g.T;
 
     // ---- phase A: candidate search, four left keypoints per pass ----
+    // The left keypoint of the NEXT pass (coordinates, level, descriptor) is requested before the current pass starts its own chain of
+    // dependent loads (bucket table -> entries -> right descriptors): one round trip less per pass.
+    struct LeftKp { int x, y, level; uint4 a0, a1; };
+    auto load_left = [&](int pass) {
+        const int i = min(blk * kpw + pass * SKPW + grp, Nl - 1);      // idle groups shadow the last keypoint and report nothing
+        const uint4 *dl = reinterpret_cast<const uint4 *>(descL + (tb + i) * 32);
+        return LeftKp{oL[i], oL[Nl + i], oL[4 * (size_t)Nl + i], dl[0], dl[1]};
+    };
+#ifndef ST_PREFETCH
+#define ST_PREFETCH 1
+#endif
+#if ST_PREFETCH
+    LeftKp nxt = load_left(0);
+#endif
     for (int pass = 0; pass < npass; pass++) {
         if (blk * kpw + pass * SKPW >= Nl) break;     // (wave-uniform)
         const int i_raw = blk * kpw + pass * SKPW + grp;
         const bool live = i_raw < Nl;
-        const int i = live ? i_raw : Nl - 1;          // idle groups shadow the last keypoint and report nothing
-        const int xL0 = oL[i], yL0 = oL[Nl + i], levelL = oL[4 * (size_t)Nl + i];
-        const float uL = (float)xL0, vL = (float)yL0;
+#if ST_PREFETCH
+        const LeftKp cur = nxt;
+        nxt = load_left(pass + 1);
+#else
+        const LeftKp cur = load_left(pass);
+#endif
+        const int levelL = cur.level;
+        const float uL = (float)cur.x, vL = (float)cur.y;
         const float minU = uL - sa.maxD, maxU = uL - 0.0f;
-        (void)yL0;
         unsigned best_key = 0xFFFFFFFFu;
         int n_cand = 0;
         {
-            const uint4 *dl = reinterpret_cast<const uint4 *>(descL + (tb + i) * 32);
-            const uint4 a0 = dl[0], a1 = dl[1];
+            const uint4 a0 = cur.a0, a1 = cur.a1;
             const int vLi = (int)vL;
             const int *rt = row_tabR + (size_t)b * g.row_tab_stride;
             if (g.epi_rows) {
