@@ -49,7 +49,8 @@ typedef struct jsorb_params {
     int fixed_multi_scale_tile_size;
     int apply_nms_ms, nms_ms_mode_gpu;
     int device_id;                   /* reference hard-wires 0 (ORBextractor.cpp:87) */
-    int max_batch;                   /* images one extract call may process (>=1); 1 = reference behaviour */
+    int max_batch;                   /* images one extract call may process (>=1); 1 = reference behaviour - such a handle lays its launches out for the
+                                        latency of ONE image (many short workgroups), a handle with max_batch > 1 for throughput */
 } jsorb_params;
 
 typedef struct jsorb_stereo_stats {
