@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
                                                const int *__restrict__ row_tabR,
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
-                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag, DeliverStereo dl, int npass)
+                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag, int npass)
 {
     __shared__ int s_lvi[JSORB_MAX_LEVELS][12];      // th, nth, row_tab_off, W, pitch, img_off, 1/th magic, tw, ntw, tile_off, 1/tw magic (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
@@ -467,9 +467,6 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         u_right[tb + i] = out_u;
         depth[tb + i] = out_d;
         best_l1[tb + i] = out_l1;
-        // single-pair call: uRight / depth also go to the pinned host mirror from here; k_median then only overwrites what its cut removes
-        // (it used to re-read all of them and deliver them itself: a chain of dependent loads in a one-workgroup kernel, ~5 us of a frame)
-        if (dl.u_host) { dl.u_host[i] = out_u; dl.d_host[i] = out_d; }
         // per-keypoint statistics; k_median reduces them per pair (per-wave global atomics on one cache line per pair
         // serialised at the L2 atomic unit and cost more than the whole matcher)
         aux[tb + i] = (n_cand & 0x7FFFFFFF) | (corr ? 0x80000000u : 0u);
@@ -576,12 +573,15 @@ __device__ __noinline__ void median_big(MedianShared &sm, const Geometry &g, con
     int removed = 0;
     for (int i = tid; i < Nl; i += 256) {
         const int d = best_l1[tb + i];
+        float u = -1.0f, z = -1.0f;
+        if (dl.u_host) { u = u_right[tb + i]; z = depth[tb + i]; }
         if (d >= 0 && !((float)d < thDist)) {
-            u_right[tb + i] = -1.0f;
-            depth[tb + i] = -1.0f;
-            if (dl.u_host) { dl.u_host[i] = -1.0f; dl.d_host[i] = -1.0f; }
+            u = -1.0f; z = -1.0f;
+            u_right[tb + i] = u;
+            depth[tb + i] = z;
             removed++;
         }
+        if (dl.u_host) { dl.u_host[i] = u; dl.d_host[i] = z; }
     }
     if (removed) atomicAdd(&sm.s_removed, removed);
     __syncthreads();
@@ -629,6 +629,19 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
             corr += (int)(a >> 31);
         }
     }
+    // Single-pair call: the final uRight / depth also go to the pinned host mirror, from THIS kernel only (one writer per host address: two
+    // kernels storing to the same pinned word - k_stereo the value, this one the cut - would rely on the order of posted PCIe writes of
+    // different kernels).  The values are requested here, with the distances, so that their latency hides behind the histogram passes
+    // (requested in the delivery loop they were a chain of dependent round trips: 14.6 us for one pair instead of 11).
+    float uu[MED_R], zz[MED_R];
+    if (dl.u_host) {
+#pragma unroll
+        for (int r = 0; r < MED_R; r++) {
+            const int i = tid + 256 * r;
+            uu[r] = -1.0f; zz[r] = -1.0f;
+            if (i < Nl) { uu[r] = u_right[tb + i]; zz[r] = depth[tb + i]; }
+        }
+    }
     cand = wave_sum_i32(cand);
     corr = wave_sum_i32(corr);
     if ((tid & 63) == 0) { atomicAdd(&sm.s_cand, cand); atomicAdd(&sm.s_corr, corr); }
@@ -641,12 +654,13 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
 #pragma unroll
     for (int r = 0; r < MED_R; r++) {
         const int i = tid + 256 * r;
-        if (d[r] >= 0 && !((float)d[r] < thDist)) {
+        const bool cut = d[r] >= 0 && !((float)d[r] < thDist);
+        if (cut) {
             u_right[tb + i] = -1.0f;
             depth[tb + i] = -1.0f;
-            if (dl.u_host) { dl.u_host[i] = -1.0f; dl.d_host[i] = -1.0f; }      // single-pair call: k_stereo delivered the values, the cut is delivered here
             removed++;
         }
+        if (dl.u_host && i < Nl) { dl.u_host[i] = cut ? -1.0f : uu[r]; dl.d_host[i] = cut ? -1.0f : zz[r]; }
     }
     if (removed) atomicAdd(&sm.s_removed, removed);
     __syncthreads();
@@ -675,7 +689,7 @@ void launch_gather_counts(const int *countsL, const int *countsR, const int *sta
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
-                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag, DeliverStereo dl)
+                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag)
 {
     // Passes of four left keypoints per wave.  More passes = fewer instructions per keypoint (phases A2 and C once per wave, fuller task lists in
     // phase B), but a wave runs its passes one after the other and each pass is a chain of dependent loads: the launch must still consist of
@@ -690,7 +704,7 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
     else if (n_pairs > 1) npass = waves(8) >= 24576 ? 8 : waves(6) >= 12288 ? 6 : waves(4) >= 12288 ? 4 : waves(2) >= 12288 ? 2 : 1;
     const int kpw = SKPW * npass;
     hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + kpw - 1) / kpw, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
-                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, dl, npass);
+                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, npass);
 }
 
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,
