@@ -652,7 +652,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
         // single image: k_detect and k_blur (independent of each other) as ONE launch - a frame is a chain of small launches whose latencies add up
         static const bool fuse_env = !(getenv("JSORB_FUSED_DETECT_BLUR") && atoi(getenv("JSORB_FUSED_DETECT_BLUR")) == 0);
-        const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0;
+        const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0 && e->detect_lds + 12 * 1024 <= 64 * 1024;      // (k_blur's 10 KB of static LDS come on top of k_detect's request)
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
         else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
         if (e->nms_ms)

@@ -1,6 +1,6 @@
 // k_stereo.hip - stereo matcher on device: row-epipolar candidate search + Hamming brute force + 11-shift 11x11 L1
-// refinement + sub-pixel parabola + depth, one wave64 per left keypoint, all pairs of a batch in ONE launch;
-// then one workgroup per pair for the 2.1 x median outlier cut.
+// refinement + sub-pixel parabola + depth, one wave64 per up to 32 left keypoints (three phases, see k_stereo below), all pairs of a
+// batch in ONE launch; then one workgroup per pair for the 2.1 x median outlier cut.
 //
 // Semantics restated (bit-exact): ORB_GPU::ORB_compute_stereo_match, src/cuda/orb_stereo_match.cu:105-580
 //   :119-140  row table: right keypoint iR covers rows [floor(y-r), ceil(y+r)], r = 2*scale[octave]
