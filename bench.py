@@ -484,8 +484,15 @@ def main():
             # the device-resident handles stay alive: handles created right after others of the process were destroyed measured 17 %
             # less in this regime (57.9 k against 70 k pairs/s, tools/micro/hs_mimic.py dev_closed / dev_closelate - device memory handed
             # back to the runtime and allocated again), which is a property of the allocation history, not of the regime
-            apply_placement()                           # pinned buffers of the streamed leg: allocated by a thread that sits on the GPU's NUMA node
-            host_streamed = measure_host_streamed(orb, torch, cfg, left_u, right_u, dev)
+            saved_affinity = os.sched_getaffinity(0)    # N = 1: the binding holds around the host-streamed leg ONLY (round-4 review: it used to stay
+            apply_placement()                           # for every later leg); pinned buffers of the leg are allocated by a thread on the GPU's NUMA node
+            try:
+                host_streamed = measure_host_streamed(orb, torch, cfg, left_u, right_u, dev)
+            finally:
+                try:
+                    os.sched_setaffinity(0, saved_affinity)
+                except OSError:
+                    pass
             for h in handles:
                 h.close()
             frame_latency = measure_frame_latency(cfg, left_u[0], right_u[0])

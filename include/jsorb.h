@@ -212,6 +212,7 @@ int jsorb_mem_stream_create(void **stream);                                  /* 
 int jsorb_mem_stream_destroy(void *stream);
 int jsorb_mem_stream_sync(void *stream);                                     /* cudaStreamSynchronize (:190) */
 int jsorb_mem_device_sync(void);                                             /* the device-wide wait cudaFree / cudaFreeHost imply (:31-44): before a buffer is recycled */
+int jsorb_mem_buffer_sync(const void *device);                               /* the same wait on the device that owns `device` (cudaFree waits for the buffer's device, not the caller's current one) */
 int jsorb_mem_h2d(void *device_dst, const void *host_src, size_t bytes);     /* cudaMemcpy HostToDevice (:96) */
 int jsorb_mem_d2h(void *host_dst, const void *device_src, size_t bytes);     /* cudaMemcpy DeviceToHost (:90) */
 int jsorb_mem_d2d(void *device_dst, const void *device_src, size_t bytes);

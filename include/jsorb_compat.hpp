@@ -242,7 +242,7 @@ private:
     void mark_stream(cudaStream_t st) { if (!own_) return; if (st == own_->stream) own_->stream_used.store(true); else own_->foreign.store(true); }
     // The reference frees with cudaFree / cudaFreeHost, which wait for the whole device; a recycled buffer must not reach its next user while
     // work the library never saw (kernels on gpu_data(), copies on the caller's streams) may still touch it: one device-wide wait then
-    static void settle(Owner *o) { if (o->foreign.load()) { jsorb_mem_device_sync(); o->foreign.store(false); } }
+    static void settle(Owner *o) { if (o->foreign.load()) { jsorb_mem_buffer_sync(o->gpu); o->foreign.store(false); } }      // (the device that owns the buffer, not the thread's current one)
     static void destroy(Owner *o)
     {
         detail::SyncedBufferCache::get().give_stream(o->stream, o->stream_used.load());      // (waits for the stream's work first, if it ever had any)

@@ -888,6 +888,7 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
             const size_t want = desc < cu_lds ? (cu_lds - desc) / 4 / gran * gran : 0;
             if (e->detect_lds <= want) e->detect_lds = want;
         }
+        if (const char *rq = getenv("JSORB_DETECT_LDS_REQUEST")) e->detect_lds = std::max(detect_lds_bytes(g), (size_t)atoi(rq));      // experiment hook: explicit request (never below what the layout needs)
     }
     e->pyr_lds = pyramid_lds_bytes(g);
     for (int i = 1; i < g.L; i++)
@@ -1022,7 +1023,7 @@ void jsorb_destroy(jsorb_extractor *e)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);
@@ -1285,14 +1286,24 @@ static int finish_single_frame(jsorb_extractor *e, int *n_keypoints)
     return JSORB_OK;
 }
 
+// The synchronous single-image calls wait for the frame themselves, so nobody needs ev_upload_read (one barrier packet less in front of the
+// match) - `sync_single` tells run_pipeline so.  The flag is reset on every way out (scope guard), and a call that fails AFTER the frame was
+// enqueued (mark_buffer_consumed / finish_single_frame) waits for the stream before it returns: the next call memcpys into the pinned upload
+// buffer without an event to wait for, and k_upload_level0 of the failed frame may still be reading it (round-4 review).
+static int extract_single_sync(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints)
+{
+    struct Reset { jsorb_extractor *e; ~Reset() { e->sync_single = false; } } reset{e};
+    e->sync_single = true;
+    int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
+    if (!rc) rc = finish_single_frame(e, n_keypoints);
+    if (rc && e->stream) (void)hipStreamSynchronize(e->stream);
+    return rc;
+}
+
 int jsorb_extract(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints)
 {
     if (!e) return JSORB_ERR_INVALID;
-    e->sync_single = true;
-    int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
-    e->sync_single = false;
-    if (rc) return rc;
-    return finish_single_frame(e, n_keypoints);
+    return extract_single_sync(e, host_image, step, n_keypoints);
 }
 
 int jsorb_extract_into(jsorb_extractor *e, const uint8_t *host_image, int step, int *n_keypoints, int32_t *dev_keypoints_dst, uint8_t *dev_descriptors_dst)
@@ -1300,13 +1311,10 @@ int jsorb_extract_into(jsorb_extractor *e, const uint8_t *host_image, int step, 
     if (!e) return JSORB_ERR_INVALID;
     e->deliver_kp_dev = dev_keypoints_dst;
     e->deliver_desc_dev = dev_descriptors_dst;
-    e->sync_single = true;
-    int rc = jsorb_extract_batch_host_async(e, host_image, 0, step, 1);
-    e->sync_single = false;
+    const int rc = extract_single_sync(e, host_image, step, n_keypoints);
     e->deliver_kp_dev = nullptr;
     e->deliver_desc_dev = nullptr;
-    if (rc) return rc;
-    return finish_single_frame(e, n_keypoints);
+    return rc;
 }
 
 int jsorb_extract_device(jsorb_extractor *e, const uint8_t *dev_image, int step, int *n_keypoints)
@@ -1728,6 +1736,21 @@ int jsorb_mem_stream_create(void **stream)
 int jsorb_mem_stream_destroy(void *stream) { if (stream) MEMCHK(hipStreamDestroy((hipStream_t)stream)); return JSORB_OK; }
 int jsorb_mem_stream_sync(void *stream) { MEMCHK(hipStreamSynchronize((hipStream_t)stream)); return JSORB_OK; }
 int jsorb_mem_device_sync(void) { MEMCHK(hipDeviceSynchronize()); return JSORB_OK; }
+// the same wait for the device that OWNS a buffer, whatever the calling thread's current device is (a SyncedMem may be released by a thread that
+// has selected another GPU); the current device is restored
+int jsorb_mem_buffer_sync(const void *device_ptr)
+{
+    int cur = -1, dev = -1;
+    MEMCHK(hipGetDevice(&cur));
+    hipPointerAttribute_t at{};
+    if (device_ptr && hipPointerGetAttributes(&at, device_ptr) == hipSuccess) dev = at.device;
+    else (void)hipGetLastError();
+    if (dev >= 0 && dev != cur) MEMCHK(hipSetDevice(dev));
+    const hipError_t rc = hipDeviceSynchronize();
+    if (dev >= 0 && dev != cur) (void)hipSetDevice(cur);
+    MEMCHK(rc);
+    return JSORB_OK;
+}
 int jsorb_mem_h2d(void *d, const void *h, size_t n) { if (n) MEMCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return JSORB_OK; }
 int jsorb_mem_d2h(void *h, const void *d, size_t n) { if (n) MEMCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return JSORB_OK; }
 int jsorb_mem_d2d(void *d, const void *s, size_t n) { if (n) MEMCHK(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice)); return JSORB_OK; }

@@ -20,6 +20,7 @@ struct StereoArgs {
 size_t detect_lds_bytes(const Geometry &g);
 
 size_t pyramid_lds_bytes(const Geometry &g);
+int pyramid_ns_dispatched(int ns16);      // the NS template argument k_pyramid runs for a level that needs ns16 loads per row (1, 2 or 4)
 int pyramid_loads_per_row(float s, int W); // 16-byte loads per lane and level-0 row in k_pyramid for a level of scale s and width W (exact, by enumeration)
 int detect_swar6_threshold(int threshold);   // k_detect: threshold of the 6-bit early rejects if they provably accept a superset of the exact ones (exhaustive check), else 0
 void fill_pyramid_layout(Geometry &g);     // rows per k_pyramid tile (pyr_th), sparse windows, workgroup table offsets (host side, once per handle)

@@ -35,7 +35,7 @@ EXPORTS = [
     "jsorb_reset_kernel_timing", "jsorb_kernel_name", "jsorb_project_points", "jsorb_hamming_pairs", "jsorb_is_in_frustum",
     "jsorb_unpack_frame", "jsorb_assign_features_to_grid", "jsorb_copy_level_mask",
     "jsorb_mem_set_device", "jsorb_mem_alloc_host", "jsorb_mem_alloc_device", "jsorb_mem_alloc_device_pitched", "jsorb_mem_free_host",
-    "jsorb_mem_free_device", "jsorb_mem_stream_create", "jsorb_mem_stream_destroy", "jsorb_mem_stream_sync", "jsorb_mem_device_sync", "jsorb_mem_h2d", "jsorb_mem_d2h",
+    "jsorb_mem_free_device", "jsorb_mem_stream_create", "jsorb_mem_stream_destroy", "jsorb_mem_stream_sync", "jsorb_mem_device_sync", "jsorb_mem_buffer_sync", "jsorb_mem_h2d", "jsorb_mem_d2h",
     "jsorb_mem_d2d", "jsorb_mem_h2d_async", "jsorb_mem_d2h_async", "jsorb_mem_d2d_async", "jsorb_mem_set_zero", "jsorb_mem_set_zero_async",
     "jsorb_mem_last_error", "jsorb_read_mask_image", "jsorb_mask_image_last_error", "jsorb_create_masked",
 ]
