@@ -105,6 +105,8 @@ struct jsorb_extractor {
     bool main_stream_dirty = false;    // this call enqueued input copies on the main stream: the lanes must fork after them
     bool counts_synced = false;        // h_counts / h_stats reflect the last enqueued batch (set by jsorb_sync)
     size_t detect_lds = 0, pyr_lds = 0;
+    size_t detect_redo_lds = 0;        // compact k_detect: dynamic LDS of k_detect_redo
+    unsigned *det_redo = nullptr;      // compact k_detect: redo lists, (2 + 2 * detect_blocks) words per image slot - a lane launch over images [f, f + m) uses the words of its slots, counter first; zero between launches
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
     // host uploads: two dense B x H0 x W0 landing buffers filled by ONE hipMemcpyAsync per batch on a dedicated copy stream, then read
@@ -652,9 +654,10 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
         // single image: k_detect and k_blur (independent of each other) as ONE launch - a frame is a chain of small launches whose latencies add up
         static const bool fuse_env = !(getenv("JSORB_FUSED_DETECT_BLUR") && atoi(getenv("JSORB_FUSED_DETECT_BLUR")) == 0);
-        const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0 && e->detect_lds + 12 * 1024 <= 64 * 1024;      // (k_blur's 10 KB of static LDS come on top of k_detect's request)
+        const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0 && !g.det_compact && e->detect_lds + 12 * 1024 <= 64 * 1024;      // (k_blur's 10 KB of static LDS come on top of k_detect's request)
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
-        else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st));
+        else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st,
+                                                       e->det_redo ? e->det_redo + (size_t)f * (2 + 2 * (size_t)g.detect_blocks) : nullptr, e->detect_redo_lds));
         if (e->nms_ms)
             JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
                                                       e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
@@ -872,9 +875,14 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
         uint8_t tr[256];
         g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !getenv("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
     }
+    // Batch handles run k_detect's compact form (score plane built late, on top of the dead image tile: 8 workgroups per CU) with k_detect_redo
+    // behind it; single-image handles the full-plane form (one image does not fill the chip, and the redo launch would sit on the frame's critical
+    // path).  JSORB_DETECT_FULLPLANE=1 gives a batch handle the full-plane form (the round-4 kernel: A/B measurements, tests).
+    g.det_compact = (!g.latency && !(getenv("JSORB_DETECT_FULLPLANE") && atoi(getenv("JSORB_DETECT_FULLPLANE")) != 0)) ? 1 : 0;
     fill_detect_layout(g);
     e->detect_lds = detect_lds_bytes(g);
-    if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
+    e->detect_redo_lds = g.det_compact ? detect_redo_lds_bytes(g) : 0;
+    if (e->detect_lds > 160 * 1024 || e->detect_redo_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
     // LDS partition of a CU in the batch pipeline (profiles/r04_lds_counters.txt, "LDS request sweep"): the lanes overlap k_detect of one image
     // group with k_describe of another, and what decides whether a k_describe workgroup can start on a CU that k_detect fills is LDS, which
     // is handed out in 1280-byte granules.  The request is therefore raised to the largest one that still lets four k_detect workgroups AND
@@ -883,7 +891,7 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     {
         hipFuncAttributes fa{};
         const size_t cu_lds = 160 * 1024, gran = 1280;
-        if (hipFuncGetAttributes(&fa, describe_kernel_address()) == hipSuccess && !getenv("JSORB_DETECT_LDS_NATURAL")) {
+        if (!g.det_compact && hipFuncGetAttributes(&fa, describe_kernel_address()) == hipSuccess && !getenv("JSORB_DETECT_LDS_NATURAL")) {
             const size_t desc = (fa.sharedSizeBytes + gran - 1) / gran * gran;
             const size_t want = desc < cu_lds ? (cu_lds - desc) / 4 / gran * gran : 0;
             if (e->detect_lds <= want) e->detect_lds = want;
@@ -910,6 +918,11 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     }
     HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
+    if (g.det_compact) {
+        const size_t n = B * (2 + 2 * (size_t)g.detect_blocks) * sizeof(unsigned);
+        HIPCHK(e, hipMalloc(&e->det_redo, n));
+        HIPCHK(e, hipMemset(e->det_redo, 0, n));
+    }
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
     HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
     HIPCHK(e, hipMalloc(&e->row_tab, B * (size_t)g.row_tab_stride * sizeof(int)));
@@ -1023,7 +1036,7 @@ void jsorb_destroy(jsorb_extractor *e)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
+                    e->out_kp, e->det_redo, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);

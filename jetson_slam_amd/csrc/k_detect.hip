@@ -22,6 +22,17 @@
 //   * phase 3 (positive scores only): 3x3 NMS from LDS and one ds_max_u32 per column with the key
 //     (score << 16 | 0xFFFF - rank), rank = ty * 256 + k : the max key IS the reference's column winner.
 //   * phase 4: the reference's horizontal tree replayed literally on <= 128 column slots in LDS.
+// Round 5 - the COMPACT form (template parameter CP, what batch handles run): the kernel's occupancy is decided by LDS (30 VGPRs, but 33 KB per
+// 4-wave workgroup = 4 waves per SIMD, half of a wave's life spent waiting), and 260 of the ~420 LDS bytes a band row costs were the u16 score
+// plane, >= 93 % zeros, alive from phase 0 on.  In the compact form a positive's score travels in its list entry (score << 16 | row << 8 | column, a
+// workgroup-wide u32 pool filled with one LDS atomic per ring-test chunk), and the plane is built only when phases 1 + 2 are over - ON TOP of the
+// image tile and the survivor lists, which are dead by then: every wave zeroes the plane rows it owned in phase 1 and scatters the pool's positives of
+// THOSE rows into them, one more barrier, then the NMS reads the plane as before (its work spread over all 256 threads by pool index).  20 KB
+// instead of 33 KB at the SAME band heights = 8 workgroups per CU (timing-only knock-out first: -27 % kernel time,
+// profiles/r05_detect_occupancy_knockout.txt).  The pool takes what the 20 KB leave (~1000 entries: 13 % of a band's pixels; the benchmark
+// images have 3-7 % positives, with single waves at 3 x the mean - per-wave lists of 192 overflowed in a third of the bands).  A band whose
+// positives do not fit cannot fall back to a dense scan - there is no plane to scan - so the workgroup hands it to a redo list, and
+// k_detect_redo, launched behind every compact launch, runs the listed bands through the full-plane form (normally: reads a zero counter and exits).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +50,23 @@ namespace jsorb {
 #define DET_LIST_CAP 640
 #endif
 #define DET_LIST_STEP 256
+// compact form: survivor-list capacity of one wave (entries) and the capacity of its list of positives (u32 entries: score << 16 | ry << 8 | rx)
+#ifndef DET_CP_LIST_CAP
+#define DET_CP_LIST_CAP 384
+#endif
+// The positives of a workgroup share ONE pool: at least DET_POS_PERMILLE of the band's region pixels (a band is only as tall as that allows,
+// fill_detect_layout) and whatever else the LDS budget leaves; a test build caps it with DET_POS_MAX.  Positives on the benchmark images:
+// 3-7 % of the pixels on average, up to 18 % in single bands of the coarse levels (checker patches) - a pool that holds less sends bands through
+// k_detect_redo, which runs serially behind the launch (measured with per-wave lists of 192: 5 % of the bands redone, kernel + 30 %).
+#define DET_POS_MIN 256
+#ifndef DET_POS_MAX
+#define DET_POS_MAX 8192
+#endif
+#ifndef DET_POS_PERMILLE
+#define DET_POS_PERMILLE 180
+#endif
+// LDS budget of a compact workgroup: 17 granules of 1280 B = 7 workgroups per CU (28 waves) and 9 granules left for another kernel's workgroup
+#define DET_CP_BUDGET (17 * 1280)
 // waves per workgroup: they share the staged tile and take its region rows in turn
 #ifndef DET_NW
 #define DET_NW 4
@@ -49,39 +77,74 @@ struct DetectLds {
     int img_stride;      // bytes per LDS image row (multiple of 16)
     int img_rows;        // th + 8
     int score_w;         // k*tw + 2
+    int score_stride;    // u16 elements per row of the score plane (compact form: rounded up to an even number - rows start on dwords)
     int score_rows;      // th + 2
     int list_cap;        // survivor-list capacity of ONE wave (entries)
-    size_t off_score, off_list, off_colkey, off_tree, total;
+    int pos_cap;         // compact form: entries of the workgroup's pool of positives
+    size_t off_score, off_list, off_pos, off_colkey, off_tree, total;
 };
 
-__host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_tiles, int ranked)
+// compact = 0: image tile | score plane | survivor lists | keys | tree        (every region alive from phase 0 to phase 3)
+// compact = 1: [image tile | survivor lists] overlaid by the score plane | lists of positives | keys | tree | overflow flag
+__host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_tiles, int ranked, int compact, size_t budget = DET_CP_BUDGET)
 {
     DetectLds d;
     const int ktw = k_tiles * tw;
     d.img_stride = DET_S;                          // fixed: window is 16-byte aligned on the left (<= 15 extra bytes), ktw <= 128
     d.img_rows = th + 8;
     d.score_w = ktw + 2;
+    d.score_stride = compact ? (d.score_w + 1) & ~1 : d.score_w;
     d.score_rows = th + 2;
     // a wave owns <= 2*ceil(rows/8) rows of the score region.  The list is CAPPED (the worst case - every pixel survives the early
     // rejects - would cost 7.8 KB at tile 30 and hold the kernel at 7 workgroups per CU): when a wave's list could not take another
     // early-reject step (DET_LIST_STEP entries), the wave runs its ring test on what it has - only positives stay in the list - and
-    // goes on; if even the positives do not fit, the wave falls back to a dense scan of its rows in phase 3.
+    // goes on; if even the positives do not fit, the wave falls back to a dense scan of its rows in phase 3 (full-plane form) or hands
+    // the band to the redo list (compact form).
     const int full = 2 * ((d.score_rows + 2 * DET_NW - 1) / (2 * DET_NW)) * d.score_w;
-    d.list_cap = full <= DET_LIST_CAP ? full : DET_LIST_CAP;
+    const int cap = compact ? DET_CP_LIST_CAP : DET_LIST_CAP;
+    d.list_cap = full <= cap ? full : cap;
     size_t o = (size_t)d.img_stride * d.img_rows;
     o = (o + 15) & ~(size_t)15;
-    d.off_score = o;
-    o += (size_t)d.score_w * d.score_rows * 2;
-    o = (o + 15) & ~(size_t)15;
-    d.off_list = o;
-    o += (size_t)(d.list_cap + 64) * DET_NW * 2;      // + 64 dump slots per wave: lanes without a survivor store there (no exec masking around the list appends)
-    o = (o + 15) & ~(size_t)15;
+    if (compact) {
+        d.off_score = 0;
+        d.off_list = o;
+        o += (size_t)(d.list_cap + 64) * DET_NW * 2;      // + 64 dump slots per wave: lanes without a survivor store there (no exec masking around the list appends)
+        const size_t plane = (size_t)d.score_stride * ((d.score_rows + 1) & ~1) * 2;      // (an even number of rows: a wave zeroes its rows in pairs)
+        if (o < plane) o = plane;
+        o = (o + 15) & ~(size_t)15;
+        d.off_pos = o;
+        // the pool of positives: DET_POS_PERMILLE of the region's pixels, or more if the budget has room left behind the plane and the fixed part
+        const size_t fixed = 128 * 4 + (ranked ? 256 : 128 * 8) + 16;
+        long cap = ((long)budget - (long)o - (long)fixed) / 4;
+        const long want = ((long)d.score_w * d.score_rows * DET_POS_PERMILLE + 999) / 1000;
+        cap = cap < want ? want : cap;
+        cap = cap < DET_POS_MIN ? DET_POS_MIN : cap;
+        cap = cap > DET_POS_MAX ? DET_POS_MAX : cap;
+        d.pos_cap = (int)cap;
+        o += (size_t)d.pos_cap * 4;
+    } else {
+        d.pos_cap = 0;
+        d.off_score = o;
+        o += (size_t)d.score_w * d.score_rows * 2;
+        o = (o + 15) & ~(size_t)15;
+        d.off_list = o;
+        o += (size_t)(d.list_cap + 64) * DET_NW * 2;
+        o = (o + 15) & ~(size_t)15;
+        d.off_pos = o;
+    }
     d.off_colkey = o;
     o += 128 * 4;
     d.off_tree = o;
     o += ranked ? 256 : 128 * 8;                   // column priorities (rank[128], inv[128]) or the literal tree's 128 slots
+    if (compact) o += 16;                          // the workgroup's overflow flag and the fill count of its pool
     d.total = o;
     return d;
+}
+__host__ __device__ inline int detect_flush_at(const DetectLds &d)
+{
+    // a list that holds the worst case (every pixel of the wave's rows survives) never needs the early ring test
+    const int full = 2 * ((d.score_rows + 2 * DET_NW - 1) / (2 * DET_NW)) * d.score_w;
+    return d.list_cap >= full ? 0x7fffffff : d.list_cap - DET_LIST_STEP;
 }
 
 // Tile rows per workgroup.  The launch-wide LDS size is set by the level with the largest tiles (level 0 unless the tile size is
@@ -91,47 +154,50 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
 #define DET_MAX_R 4
 void fill_detect_layout(Geometry &g)
 {
+    const int cp = g.det_compact;
     size_t budget = 0;
-    for (int i = 0; i < g.L; i++) budget = std::max(budget, detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok).total);
-    // The allocation may grow to just under a fifth of a CU's LDS if that lets more tile rows share a workgroup: every wave pays a prologue
-    // of ~230 scalar + ~150 vector instructions, and the scalar pipe is nearly as busy as the vector pipes in this kernel.  Measured at the
+    for (int i = 0; i < g.L; i++) budget = std::max(budget, detect_lds_layout(g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok, cp, 0).total);      // (budget 0: the smallest pool the level may have)
+    // Full-plane form: the allocation may grow to just under a fifth of a CU's LDS if that lets more tile rows share a workgroup: every wave pays a
+    // prologue of ~230 scalar + ~150 vector instructions, and the scalar pipe is nearly as busy as the vector pipes in this kernel.  Measured at the
     // end of round 3 (pairs/s at C2 / C3 / C5): 7 workgroups per CU (the round-2 choice) 107.1 / 80.6 / 30.8 k, 6: 109.7 / 84.9 / 31.7 k,
-    // 5: 111.7 / 85.5 / 32.0-32.3 k, 4: 109.5 / 85.7 / 31.6 k.  The kernel's own duration barely moves; what the fewer, larger workgroups
-    // leave of a CU goes to the kernels of the other lanes.  Round 4: with the lists' dump slots the layout at this budget lands on 26
-    // LDS granules (33280 B), i.e. FOUR k_detect workgroups per CU plus exactly the 30720 B of one k_describe workgroup - jsorb_create
-    // raises the request to that size on purpose (see there); a larger band budget than this one changes nothing measurable.
+    // 5: 111.7 / 85.5 / 32.0-32.3 k, 4: 109.5 / 85.7 / 31.6 k.
+    // Compact form (round 5): the same band heights cost ~21 KB with a pool for 18 % positives: the budget is 17 granules - 7 workgroups = 7 waves per SIMD.
     if (const char *b7 = getenv("JSORB_DETECT_BUDGET")) budget = std::max(budget, (size_t)atoi(b7));
-    else budget = std::max(budget, (size_t)(160 * 1024 / 5 - 256));
+    else budget = std::max(budget, cp ? (size_t)DET_CP_BUDGET : (size_t)(160 * 1024 / 5 - 256));
     int dblk = 0;
     for (int i = 0; i < g.L; i++) {
         LevelDesc &lv = g.lv[i];
         int R = 1;
         // only the arg-max form of the tile reduction (tree_rank_ok) handles several tile rows; keys: R * k_tiles <= 128 slots, row index < 256
         while (lv.tree_rank_ok && R < DET_MAX_R && R < lv.nth && (R + 1) * lv.k_tiles <= 128 && (R + 1) * lv.th + 2 <= 255 &&
-               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1).total <= budget && !getenv("JSORB_DETECT_NO_BANDS") && !g.latency)      // single-image handles: one tile row per workgroup
+               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1, cp, 0).total <= budget && !getenv("JSORB_DETECT_NO_BANDS") && !g.latency)      // single-image handles: one tile row per workgroup
             R++;
         lv.det_R = R;
         lv.detect_blk0 = dblk;
         dblk += ((lv.nth + R - 1) / R) * lv.groups_per_row;
-        const DetectLds d = detect_lds_layout(R * lv.th, lv.tw, lv.k_tiles, lv.tree_rank_ok);
-        lv.det_score_w = d.score_w; lv.det_score_rows = d.score_rows; lv.det_img_rows = d.img_rows; lv.det_list_cap = d.list_cap;
-        // a list that holds the worst case (every pixel of the wave's rows survives) never needs the early ring test or the dense fallback
-        const int full = 2 * ((d.score_rows + 2 * DET_NW - 1) / (2 * DET_NW)) * d.score_w;
-        lv.det_flush_at = d.list_cap >= full ? 0x7fffffff : d.list_cap - DET_LIST_STEP;
-        lv.det_off_score = (int)d.off_score; lv.det_off_list = (int)d.off_list; lv.det_off_colkey = (int)d.off_colkey; lv.det_off_tree = (int)d.off_tree;
+        const DetectLds d = detect_lds_layout(R * lv.th, lv.tw, lv.k_tiles, lv.tree_rank_ok, cp, budget);
+        lv.det_score_w = d.score_w; lv.det_score_stride = d.score_stride; lv.det_score_rows = d.score_rows; lv.det_img_rows = d.img_rows; lv.det_list_cap = d.list_cap;
+        lv.det_flush_at = detect_flush_at(d);
+        lv.det_pos_cap = d.pos_cap;
+        lv.det_off_score = (int)d.off_score; lv.det_off_list = (int)d.off_list; lv.det_off_pos = (int)d.off_pos; lv.det_off_colkey = (int)d.off_colkey; lv.det_off_tree = (int)d.off_tree;
     }
     g.detect_blocks = dblk;
 }
 
-size_t detect_lds_bytes(const Geometry &g)
+// dynamic LDS of the primary launch (the handle's form) and of the redo launch (the full-plane form on the SAME bands)
+static size_t detect_lds_bytes_form(const Geometry &g, int compact)
 {
     size_t m = 0;
     for (int i = 0; i < g.L; i++) {
-        DetectLds d = detect_lds_layout(g.lv[i].det_R * g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok);
+        DetectLds d = detect_lds_layout(g.lv[i].det_R * g.lv[i].th, g.lv[i].tw, g.lv[i].k_tiles, g.lv[i].tree_rank_ok, compact, 0);
+        if (compact) d.total += (size_t)(g.lv[i].det_pos_cap - d.pos_cap) * 4;      // the pool as fill_detect_layout sized it
         if (d.total > m) m = d.total;
     }
     return m;
 }
+size_t detect_lds_bytes(const Geometry &g) { return detect_lds_bytes_form(g, g.det_compact); }
+size_t detect_redo_lds_bytes(const Geometry &g) { return detect_lds_bytes_form(g, 0); }
+int detect_pos_cap(const Geometry &g, int level) { return g.lv[level].det_pos_cap; }
 
 // Early rejects on 6-bit pixels (k_detect phase 1, SWAR form): with q(x) = x >> 2 and t4 = (th + 1) >> 2,
 //   p > v + th  =>  q(p) - q(v) >= t4        and        p < v - th  =>  q(v) - q(p) >= t4
@@ -186,9 +252,11 @@ extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
 
 // one workgroup of k_detect: image b, workgroup blk of the image's g.detect_blocks (a kernel of its own for batches, one half of the fused
 // k_detect_blur launch for single frames - both below)
-template <bool HAS_MASK, bool COMPASS, bool SWAR>
+// CP: the compact form (see the head of the file); `redo` (CP only): the workgroup's band goes there if a wave's positives overflow -
+// redo[0] = number of listed bands, redo[2 + 2 i] = image, redo[3 + 2 i] = workgroup (k_detect_redo consumes and resets the list)
+template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP, bool REDO = false>
 __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk)
+                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk, unsigned *redo = nullptr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
@@ -208,11 +276,22 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const int xg0 = grp * ktw;            // first image column of the tile group
     const int y0 = r * th;                // first image row of the band
     DetectLds L;
-    L.img_stride = DET_S; L.img_rows = lv.det_img_rows; L.score_w = lv.det_score_w; L.score_rows = lv.det_score_rows; L.list_cap = lv.det_list_cap;
-    L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
+    int flush_at;                                         // wave-uniform; INT_MAX when the list holds the worst case (no early ring test)
+    static_assert(!(CP && REDO), "the redo pass runs the full-plane form");
+    if constexpr (!REDO) {                                // the handle's own form: the host has laid it out (fill_detect_layout)
+        L.img_stride = DET_S; L.img_rows = lv.det_img_rows; L.score_w = lv.det_score_w; L.score_stride = lv.det_score_stride; L.score_rows = lv.det_score_rows; L.list_cap = lv.det_list_cap;
+        L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_pos = (size_t)lv.det_off_pos; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
+        flush_at = lv.det_flush_at;
+    } else {                                              // k_detect_redo on a compact handle: the full-plane layout of the same band (rare path: computed here)
+        L = detect_lds_layout(R * th1, lv.tw, lv.k_tiles, lv.tree_rank_ok, 0);
+        flush_at = detect_flush_at(L);
+    }
     unsigned char *s_img = smem;
     unsigned short *s_score = reinterpret_cast<unsigned short *>(smem + L.off_score);
     unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
+    unsigned *s_pos = reinterpret_cast<unsigned *>(smem + L.off_pos);                              // CP: the workgroup's pool of positives
+    unsigned *s_overflow = reinterpret_cast<unsigned *>(smem + L.off_tree + (lv.tree_rank_ok ? 256 : 1024));      // CP: [0] != 0 - the positives did not fit the pool; [1] entries in the pool
+    const int pos_cap = CP ? lv.det_pos_cap : 0;
     unsigned *s_colkey = reinterpret_cast<unsigned *>(smem + L.off_colkey);
     unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
 
@@ -244,9 +323,11 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         }
     }
     {
-        const int nsc = (L.score_w * L.score_rows * 2 + 15) >> 4;
-        uint4 *z = reinterpret_cast<uint4 *>(s_score);
-        for (int i = tid; i < nsc; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+        if constexpr (!CP) {                              // (compact form: the plane does not exist yet - it is built after phase 2, where the image tile is now)
+            const int nsc = (L.score_w * L.score_rows * 2 + 15) >> 4;
+            uint4 *z = reinterpret_cast<uint4 *>(s_score);
+            for (int i = tid; i < nsc; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+        } else if (tid < 2) s_overflow[tid] = 0u;
         if (tid < 128) s_colkey[tid] = 0;
         if (lv.tree_rank_ok && tid < 64) reinterpret_cast<unsigned *>(s_tree)[tid] = lut_bits[ctab_tree(g) + 64 * lvl + tid];      // column priorities
     }
@@ -299,9 +380,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const int ry_lo = max(0, JSORB_BORDER - (y0 - 1)), ry_hi = min(L.score_rows - 1, H - JSORB_BORDER - 1 - (y0 - 1));      // region rows inside the image's interior (wave-uniform)
     const int e_lane = (sub << 8) + (cb - c0);                                           // list entry of the lane's first pixel in row `sub`
     const int min_pop = g.lut_min_pop;
-    const int flush_at = lv.det_flush_at;                 // wave-uniform; INT_MAX when the list holds the worst case (no early ring test, no dense fallback)
     int n_pos = 0;                                        // wave-uniform: positives at the front of the list
-    bool dense = false;                                   // wave-uniform: the positives overflowed, phase 3 scans this wave's rows densely
+    bool dense = false;                                   // wave-uniform: the positives overflowed - full-plane form: phase 3 scans this wave's rows densely; compact form: the band goes to the redo list
     // ---- phase 2 (called when the list could not take another early-reject step, and once at the end): full 16-ring test + score,
     // each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
@@ -309,13 +389,18 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 #ifdef DET_TIMING
     unsigned long long t_ring = 0;
 #endif
-    auto ring_pass = [&]() {
+    // Compact form: the pending survivors are the whole list [0, n_mine); a pass takes full chunks of 64 from its END (the order of the entries is
+    // free) and leaves the < 64 others pending unless it is the wave's last pass, so every ring test but the last one runs on a full wave; a positive goes
+    // to the wave's list of positives with its score.  When that list could not take another chunk the wave gives up: the band goes to the redo list.
+    auto ring_pass = [&](bool last) {
         DET_T(t_r0);
-        for (int i0 = n_pos; i0 < n_mine; i0 += 64) {
+        (void)last;
+        for (int i0 = CP ? n_mine - 64 : n_pos; CP ? (n_mine > 0 && (last || i0 >= 0)) : i0 < n_mine; i0 += CP ? -64 : 64) {
             const int i = i0 + lane;
             bool hit = false;
             int e = 0;
-            if (i < n_mine) {
+            unsigned sad = 0;
+            if (CP ? i >= 0 : i < n_mine) {
                 e = my_list[i];
                 const int ry = e >> 8, rx = e & 255;
                 const unsigned char *c = s_img + (ry + 3) * S + lx_off + rx;
@@ -355,18 +440,33 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                 hit = (lb & 1u) != 0;
                 if (hit) {
                     const unsigned v2 = (unsigned)v * 0x10001u;
-                    unsigned sad = 0;
 #pragma unroll
                     for (int k = 0; k < 8; k++) sad = __builtin_amdgcn_sad_u16(P[k], v2, sad);
-                    s_score[__umul24(ry, L.score_w) + rx] = (unsigned short)sad;
+                    if constexpr (!CP) s_score[__umul24(ry, L.score_w) + rx] = (unsigned short)sad;
                 }
             }
             const unsigned long long bal = __ballot(hit);
-            if (hit && !dense) (my_list + n_pos)[__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
+            const unsigned rank_in_chunk = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if constexpr (CP) {
+                n_mine = i0 > 0 ? i0 : 0;
+                if (bal != 0ull) {
+                    // room in the workgroup's pool for the chunk's positives: one LDS atomic by one lane, its result through an SGPR
+                    const unsigned cnt = (unsigned)__popcll(bal);
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(s_overflow + 1, cnt);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base + cnt > (unsigned)pos_cap) { dense = true; n_mine = 0; break; }      // the band is redone by k_detect_redo
+                    if (hit) (s_pos + base)[rank_in_chunk] = (sad << 16) | (unsigned)e;      // (a score is <= 16 * 255 = 4080)
+                }
+            } else {
+                if (hit && !dense) (my_list + n_pos)[rank_in_chunk] = (unsigned short)e;
+            }
             n_pos += __popcll(bal);
         }
-        if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
-        n_mine = n_pos;
+        if constexpr (!CP) {
+            if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
+            n_mine = n_pos;
+        }
 #ifdef DET_TIMING
         t_ring += __builtin_amdgcn_s_memtime() - t_r0;
 #endif
@@ -385,13 +485,16 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     }
     const int rb_end = min(L.score_rows, H - JSORB_BORDER - (y0 - 1));               // rbase < rb_end: the region and the image's interior
 #if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 2
-#define DET_RING_PASS() do { n_mine = 0; } while (0)
+#define DET_RING_PASS(last) do { n_mine = 0; } while (0)
 #else
-#define DET_RING_PASS() ring_pass()
+#define DET_RING_PASS(last) ring_pass(last)
 #endif
     int e_cur = (rb_first << 8) + e_lane;                  // list entry of the lane's first pixel in the current step
     for (int rbase = rb_first; rbase < rb_end; rbase += step_rows) {
-        if (n_mine > flush_at) DET_RING_PASS();
+        if (n_mine > flush_at) {
+            DET_RING_PASS(false);
+            if (CP && dense) break;                      // the wave has given up (its positives do not fit): the band is redone by k_detect_redo
+        }
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
         const unsigned *rowp = reinterpret_cast<const unsigned *>(lane_img + (rbase + 3) * S);
@@ -491,19 +594,57 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             }
         }
     }
-    DET_RING_PASS();
+    DET_RING_PASS(true);
 #undef DET_RING_PASS
 #undef PK
     DET_T(t_p2);
 #ifdef DET_TIMING
     DET_TACC(3, t_p1 + t_ring, t_p2); DET_TACC(4, 0ull, t_ring);
 #endif
+    if constexpr (CP) {
+        if (dense && lane == 0) s_overflow[0] = 1u;
+    }
     __syncthreads();
     DET_T(t_p3);
     DET_TACC(5, t_p2, t_p3);
 #if defined(DET_KNOCKOUT) && (DET_KNOCKOUT == 2 || DET_KNOCKOUT == 3)
     if (tile_out) return;
 #endif
+    if constexpr (CP) {
+        // ---- compact form: a band with a wave that gave up is listed for k_detect_redo; otherwise the score plane is built now, where the image tile
+        // and the survivor lists were (every wave is past them) ----
+        if (s_overflow[0] != 0u) {                        // (one LDS word: the same for every thread of the workgroup)
+            if (tid == 0) {
+                const unsigned slot = atomicAdd(redo, 1u);
+                redo[2 + 2 * slot] = (unsigned)b;
+                redo[3 + 2 * slot] = (unsigned)blk;
+            }
+            return;
+        }
+        // A wave zeroes the plane rows it owned in phase 1 (rows rbase .. rbase + rows_per_step - 1 of every DET_NW-th step, border steps included)
+        // and then scatters its own positives - which lie in exactly those rows - into them: LDS operations of one wave execute in order, so the
+        // only barrier needed is the one in front of the NMS, which reads the neighbours' rows.
+        {
+            const int sstr = L.score_stride;              // even: a row is sstr / 2 dwords and starts on a dword
+            unsigned *const plane32 = reinterpret_cast<unsigned *>(s_score);
+            const int dw_per_step = (rows_per_step * sstr) >> 1;         // <= 130
+            for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += DET_NW * rows_per_step) {
+                unsigned *const row = plane32 + ((rbase * sstr) >> 1);      // (two_rows: rbase is even; else one row of sstr / 2 dwords)
+                if (lane < dw_per_step) row[lane] = 0u;                      // (never beyond the wave's own rows: the next ones belong to a wave that may already be scattering)
+                if (lane + 64 < dw_per_step) row[lane + 64] = 0u;
+                if (lane + 128 < dw_per_step) row[lane + 128] = 0u;
+            }
+            // the pool holds the positives of all four waves in the order the chunks arrived: a wave takes the ones of ITS rows
+            const int n_all = (int)s_overflow[1];
+            const int own_sh = two_rows ? 1 : 0;
+            for (int i = lane; i < n_all; i += 64) {
+                const unsigned e = s_pos[i];
+                const unsigned ry = (e >> 8) & 255u;
+                if (((ry >> own_sh) & (DET_NW - 1)) == (unsigned)wave) s_score[__umul24(ry, (unsigned)sstr) + (e & 255u)] = (unsigned short)(e >> 16);
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + arg-max key, positives of the wave's own list ----
     // (list entries always have a positive score; the `s > 0` test only matters for the dense fallback)
@@ -511,16 +652,16 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     // the smaller (ty, k).  When the host has verified that the tree is an arg-max with a fixed column priority (tree_rank_ok),
     // one ds_max_u32 per positive on a per-TILE key (score << 18 | 127 - column priority << 11 | 2047 - row rank) yields the
     // tile winner directly; otherwise the key is per column and phase 4 replays the tree.
-    const int SW = L.score_w;
+    const int SW = L.score_stride;            // (element stride of the plane: score_w, rounded up to even in the compact form)
     const int n_ty = lv.n_ty, recip_nty = lv.recip_nty, recip_tw = lv.recip_tw;
     int kt_nms = lv.k_tiles;
     asm volatile("" : "+s"(kt_nms));          // opaque: otherwise the compiler re-loads it from the kernel arguments inside the loop below (a scalar memory round trip per iteration)
     const bool ranked = lv.tree_rank_ok != 0;
     const unsigned char *s_rank = reinterpret_cast<const unsigned char *>(s_tree);      // rank[128], inv[128]
-    auto nms_one = [&](int ry, int rx) {
+    auto nms_one = [&](int ry, int rx, int s_known) {
         if (ry < 1 || ry > th || rx < 1 || rx > ktw) return;          // halo entries only serve as neighbours
         const unsigned short *q = s_score + __umul24(ry, SW) + rx;     // (24-bit multiplies: v_mul_lo_u32 issues at a quarter of the rate)
-        const int s = q[0];
+        const int s = CP ? s_known : q[0];
         const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
                            s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];      // (all nine reads at once + one maximum + one branch: measured 0.9 % slower, rounds 3 and 4)
         if (!valid) return;
@@ -538,17 +679,23 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             atomicMax(&s_colkey[rx - 1], ((unsigned)s << 16) | (0xFFFFu - rank));
         }
     };
-    if (!dense) {
+    if constexpr (CP) {
+        const int n_all = (int)s_overflow[1];
+        for (int i = tid; i < n_all; i += DET_THREADS) {      // by pool index: every thread of the workgroup takes its share, whichever wave found the positive
+            const unsigned e = s_pos[i];
+            nms_one((int)((e >> 8) & 255u), (int)(e & 255u), (int)(e >> 16));
+        }
+    } else if (!dense) {
         for (int i = lane; i < n_pos; i += 64) {
             const int e = my_list[i];
-            nms_one(e >> 8, e & 255);
+            nms_one(e >> 8, e & 255, 0);
         }
     } else {
         // the wave's positives did not fit its list (a tile of almost nothing but corners): every pixel of the rows this wave owned
         // in phase 1 is looked at; s_score holds 0 wherever there is no corner
         for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += DET_NW * rows_per_step)
             for (int ry = rbase; ry < rbase + rows_per_step && ry < L.score_rows; ry++)
-                for (int rx = lane; rx < SW; rx += 64) nms_one(ry, rx);
+                for (int rx = lane; rx < L.score_w; rx += 64) nms_one(ry, rx, 0);
     }
     DET_T(t_p3e);
     __syncthreads();
@@ -665,51 +812,83 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     }
 }
 
-template <bool HAS_MASK, bool COMPASS, bool SWAR>
+template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP>
 __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images)
+                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images, unsigned *redo)
 {
     // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
     // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
     asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
     int b, blk;
     if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
-    detect_workgroup<HAS_MASK, COMPASS, SWAR>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk);
+    detect_workgroup<HAS_MASK, COMPASS, SWAR, CP>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk, redo);
+}
+
+// Behind every compact launch: the bands whose positives did not fit a wave's list, through the full-plane form (whose waves fall back to a dense
+// scan of their rows, so it always finishes).  Normally redo[0] == 0 and the launch is a few hundred workgroups that read one word and leave.
+// The last workgroup to finish resets the list for the lane's next batch (redo[1] counts the workgroups that are done).
+template <bool HAS_MASK, bool COMPASS, bool SWAR>
+__global__ __launch_bounds__(DET_THREADS) void k_detect_redo(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
+                                                     const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, unsigned *redo)
+{
+    const unsigned n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const int b = (int)__builtin_amdgcn_readfirstlane(redo[2 + 2 * i]), blk = (int)__builtin_amdgcn_readfirstlane(redo[3 + 2 * i]);
+        detect_workgroup<HAS_MASK, COMPASS, SWAR, false, true>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk);
+        __syncthreads();                                  // the next band re-uses the LDS
+    }
+    if (n != 0u && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0u; redo[1] = 0u; }      // every workgroup has read n and finished its bands
+    }
 }
 
 // Single frames: k_blur does not depend on k_detect (both read the pyramid), and a frame is a chain of small launches whose latencies add up -
 // so the two run as ONE launch: workgroups [0, detect_blocks) are k_detect's, the rest k_blur's (both 256 threads; LDS = k_detect's dynamic
 // part + k_blur's static 10 KB, registers = the larger of the two - irrelevant for one image, which does not fill the chip).  A frame's
 // chain is then upload - pyramid - detect+blur - compact - describe: one launch and k_blur's ~8 us less on the critical path.
+// (Full-plane form only: single-image handles; a batch handle that is handed one image runs its compact launches.)
 static_assert(DET_THREADS == BLUR_THREADS, "the fused launch runs both kinds of workgroups with one block size");
 template <bool HAS_MASK, bool COMPASS, bool SWAR>
 __global__ __launch_bounds__(DET_THREADS) void k_detect_blur(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                      const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, uint8_t *blur_slab)
 {
     const int blk = (int)blockIdx.x;
-    if (blk < g.detect_blocks) detect_workgroup<HAS_MASK, COMPASS, SWAR>(g, src, slab, mask_slab, lut_bits, tile_out, 0, blk);
+    if (blk < g.detect_blocks) detect_workgroup<HAS_MASK, COMPASS, SWAR, false>(g, src, slab, mask_slab, lut_bits, tile_out, 0, blk);
     else blur_workgroup(g, src, slab, blur_slab, lut_bits, 0, blk - g.detect_blocks);
 }
 
+#define DETECT_DISPATCH(LAUNCH)                                                                                     \
+    do {                                                                                                            \
+        if (g.has_mask) { if (!g.lut_compass) LAUNCH(true, false, false); else if (g.det_swar_t4 > 0) LAUNCH(true, true, true); else LAUNCH(true, true, false); }        \
+        else            { if (!g.lut_compass) LAUNCH(false, false, false); else if (g.det_swar_t4 > 0) LAUNCH(false, true, true); else LAUNCH(false, true, false); }     \
+    } while (0)
+
+// redo: the lane's redo list (compact handles; 2 + 2 * n_images * detect_blocks words, zero before the first launch) - the redo pass follows on the same stream
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
-                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s)
+                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s, unsigned *redo, size_t redo_lds_bytes)
 {
-#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images)
-#define DETECT_LAUNCH2(M) do { if (g.det_swar_t4 > 0) DETECT_LAUNCH(M, true, true); else DETECT_LAUNCH(M, true, false); } while (0)
-    if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH2(true); else DETECT_LAUNCH(true, false, false); }
-    else            { if (g.lut_compass) DETECT_LAUNCH2(false); else DETECT_LAUNCH(false, false, false); }
-#undef DETECT_LAUNCH2
+    if (g.det_compact) {
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, true>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, redo)
+        DETECT_DISPATCH(DETECT_LAUNCH);
 #undef DETECT_LAUNCH
+        const long total = (long)g.detect_blocks * n_images;
+        const unsigned grid = (unsigned)std::min<long>(total, 256);
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect_redo<M, C, S>), dim3(grid), dim3(DET_THREADS), redo_lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, redo)
+        DETECT_DISPATCH(DETECT_LAUNCH);
+#undef DETECT_LAUNCH
+    } else {
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, false>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, (unsigned *)nullptr)
+        DETECT_DISPATCH(DETECT_LAUNCH);
+#undef DETECT_LAUNCH
+    }
 }
 
 void launch_detect_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab, const uint32_t *lut_bits,
                         unsigned long long *tile_out, uint8_t *blur_slab, size_t lds_bytes, hipStream_t s)
 {
 #define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect_blur<M, C, S>), dim3(g.detect_blocks + g.blur_blocks), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, blur_slab)
-#define DETECT_LAUNCH2(M) do { if (g.det_swar_t4 > 0) DETECT_LAUNCH(M, true, true); else DETECT_LAUNCH(M, true, false); } while (0)
-    if (g.has_mask) { if (g.lut_compass) DETECT_LAUNCH2(true); else DETECT_LAUNCH(true, false, false); }
-    else            { if (g.lut_compass) DETECT_LAUNCH2(false); else DETECT_LAUNCH(false, false, false); }
-#undef DETECT_LAUNCH2
+    DETECT_DISPATCH(DETECT_LAUNCH);
 #undef DETECT_LAUNCH
 }
 

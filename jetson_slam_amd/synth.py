@@ -82,3 +82,56 @@ def synth_stereo_pair(seed, height=480, width=752):
 
 def synth_image(seed, height=480, width=752):
     return synth_stereo_pair(seed, height, width)[0]
+
+
+def synth_adversarial_pair(seed, height=480, width=752):
+    """A stereo pair whose RIGHT image is built by row bands so that the rarely taken branches of the stereo matcher's tail are exercised
+    (tools/ptx_chain.py chain `i`, tests/test_ptx_chain.py; every synthetic pair above has a positive disparity of 6-30 px everywhere):
+      band 0  rows [0, 5H/24)      right == left bit for bit, no noise, plus mirror-symmetric features (ends of thin vertical bars): zero disparity, and
+                                   where the L1 sums left and right of the minimum tie, a disparity of exactly 0 -> the `disparity <= 0 -> 0.01` branch,
+                                   the one double-precision expression of the path (orb_stereo_match.cu:538-545)
+      band 1  rows [5H/24, 9H/24)  content shifted the WRONG way (disparity -7): candidates outside [uL - maxD, uL], wrong or no matches
+      band 2  rows [9H/24, 13H/24) disparities 19..22, around maxD when the chain's fx is 20 (maxD = mbf / mb = fx): candidates inside the window whose
+                                   refined disparity ends up on either side of maxD
+      band 3a rows [13H/24, 16H/24) no noise, right = mean of the left content shifted by 8 and by 9 px (a half-pixel disparity): the L1 sums of the two
+                                   neighbouring shifts tie exactly (deltaR = +-0.5)
+      band 3b rows [16H/24, 19H/24) ordinary disparities 4..16 with noise (so that the median cut has a population)
+      band 4  rows [19H/24, H)     a comb of identical thin bars with period 12 and disparity 3: the best ORB candidate is often a whole period away,
+                                   the L1 minimum then sits on the edge of the +-5 window (bestR == 0 / 10 -> rejected) or ties with its neighbour
+    Returns (left, right) uint8."""
+    clean = _clean_left(seed, height, width)
+    b = [0, 5 * height // 24, 9 * height // 24, 13 * height // 24, 19 * height // 24, height]
+    # band 0: symmetric bar ends on a light background patch, dark bars of width 3 / 5, every 37 px, rows chosen per bar
+    u = _stream(seed, 7, 4 * 64)
+    y_lo, y_hi = b[0] + 24, b[1] - 30
+    k = 0
+    for x0 in range(30, width - 30, 37):
+        wbar = 3 if (k & 1) else 5
+        ytop = int(_uniform_int(u[k:k + 1], y_lo, max(y_lo, y_hi - 20))[0])
+        clean[max(0, ytop - 12):ytop + 26, x0 - 12:x0 + 12 + wbar] = 200
+        clean[ytop:ytop + 26, x0:x0 + wbar] = 30
+        k += 1
+    # band 4: comb
+    yb = b[4]
+    clean[yb:, :] = 150
+    for x0 in range(24, width - 24, 12):
+        top = yb + 22 + 14 * ((x0 // 12) % 3)
+        clean[top:min(height, top + 40), x0:x0 + 3] = 40
+    left = np.clip(clean + _noise(seed, 3, height, width, 3), 0, 255).astype(np.uint8)
+    left[b[0]:b[1]] = np.clip(clean[b[0]:b[1]], 0, 255).astype(np.uint8)          # band 0: no noise
+    b3a = 16 * height // 24
+    left[b[3]:b3a] = np.clip(clean[b[3]:b3a], 0, 255).astype(np.uint8)            # band 3a: no noise
+    d = np.zeros(height, np.int64)
+    d[b[1]:b[2]] = -7
+    d[b[2]:b[3]] = 19 + (np.arange(b[2], b[3]) // 5) % 4
+    d[b[3]:b3a] = 8
+    rows3 = np.arange(b3a, b[4])
+    d[b3a:b[4]] = 4 + (12 * (rows3 - b3a)) // max(1, b[4] - b3a)
+    d[b[4]:] = 3
+    cols = np.clip(np.arange(width)[None, :] + d[:, None], 0, width - 1)
+    shifted = np.take_along_axis(clean, cols, axis=1)
+    right = np.clip(shifted + _noise(seed, 4, height, width, 2), 0, 255).astype(np.uint8)
+    right[b[0]:b[1]] = left[b[0]:b[1]]
+    cols9 = np.clip(np.arange(width)[None, :] + 9, 0, width - 1) + np.zeros((b3a - b[3], 1), np.int64)
+    right[b[3]:b3a] = np.clip((shifted[b[3]:b3a] + np.take_along_axis(clean[b[3]:b3a], cols9, axis=1) + 1) // 2, 0, 255).astype(np.uint8)
+    return left, right
