@@ -269,6 +269,7 @@ def main():
     gathered = [torch.zeros_like(counts_bufs[0]) for _ in range(world)] if world > 1 else None
     step_no = [0]
     mb = bf / fx
+    ag_probe = [None]                             # diagnostic steps: a list that collects (start, end) of every all_gather (events on torch's stream; wall clock under gloo)
 
     def step(which=None):
         si = cur_set[0] if which is None else which
@@ -291,11 +292,20 @@ def main():
             if gloo:
                 host = counts_d.cpu()
                 parts = [torch.zeros_like(host) for _ in range(world)]
+                t_ag = time.perf_counter()
                 dist.all_gather(parts, host)
+                if ag_probe[0] is not None:
+                    ag_probe[0].append((t_ag, time.perf_counter()))
                 for g_, p_ in zip(gathered, parts):
                     g_.copy_(p_)
             else:
+                if ag_probe[0] is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(torch_stream)
                 dist.all_gather(gathered, counts_d)
+                if ag_probe[0] is not None:
+                    e1.record(torch_stream)
+                    ag_probe[0].append((e0, e1))
             ev = torch.cuda.Event()
             ev.record(torch_stream)
             counts_free[k] = ev
@@ -315,11 +325,14 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
+        blocks_local.append(dt)                   # this rank's own clock (the line reports every rank's median next to the max the value is made of)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    blocks_local = []
 
     for _ in range(args.warmup):
         step()
@@ -373,6 +386,25 @@ def main():
         parity = bool(flag.item())
     else:
         parity = parity_local
+
+    # ---- what makes the first real multi-GPU run diagnosable: every rank's own median block time, and the time of the all_gather itself ----
+    multi_diag = None
+    if world > 1:
+        ag_probe[0] = []
+        for _ in range(12):
+            step()
+        fence()
+        if gloo:
+            ag_ms = [(b - a) * 1e3 for a, b in ag_probe[0]]
+        else:
+            ag_ms = [a.elapsed_time(b) for a, b in ag_probe[0]]
+        ag_probe[0] = None
+        mine = {"median_block_ms": round(median(blocks_local) * 1e3, 3), "ms_per_step": round(median(blocks_local) / args.steps * 1e3, 4),
+                "all_gather_ms_mean": round(float(np.mean(ag_ms[2:])), 4), "all_gather_ms_max": round(float(np.max(ag_ms[2:])), 4)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        multi_diag = {"per_rank": per_rank, "all_gather_clock": "wall clock around dist.all_gather (gloo)" if gloo else "events on torch's stream around dist.all_gather (RCCL)",
+                      "note": "value is made of the MAX over ranks of each block; per_rank holds every rank's own median"}
 
     # ---- BASELINE C4 shape as a side measurement: 64 pairs per iteration over all GPUs, one all_gather per iteration ----
     c4 = None
@@ -495,7 +527,7 @@ def main():
                     pass
             for h in handles:
                 h.close()
-            frame_latency = measure_frame_latency(cfg, left_u[0], right_u[0])
+            frame_latency = measure_frame_latency(cfg, left_u[:4], right_u[:4])
             if args.config == "c2" and args.tile <= 0 and not strong:
                 # BASELINE C3 / C5 and the "nominal feature count" tiles of SURVEY 8(d), ~1 s each, every unique pair checked
                 other = {}
@@ -521,7 +553,7 @@ def main():
             "timing": {"blocks": len(blocks), "block_steps": args.steps, "measured_s": round(sum(blocks), 3), "statistic": "median block, max over ranks",
                        "block_ms_min": round(min(blocks) * 1e3, 3), "block_ms_max": round(max(blocks) * 1e3, 3)},
             "parity_vs_oracle": parity, "parity_pairs_checked": n_unique * n_sets * world, "gathered_counts_ok": counts_ok if world > 1 else None,
-            "roofline": roof, "cpu_baseline": cpu, "host_streamed": host_streamed, "frame_latency_us": frame_latency, "c4_batch64": c4,
+            "roofline": roof, "cpu_baseline": cpu, "host_streamed": host_streamed, "frame_latency_us": frame_latency, "c4_batch64": c4, "multi_gpu_diag": multi_diag,
             "other_configs": other, "rccl_init_s": None if rccl_init_s is None else round(rccl_init_s, 3),
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "placement": placements if world > 1 else [placement_info[0]],
@@ -740,7 +772,8 @@ def measure_host_streamed(orb, torch, cfg, left_u, right_u, dev, P=256, seconds=
 
 def measure_frame_latency(cfg, left, right, frames=300):
     """north-star regime: ONE stereo pair per call through the reference-shaped synchronous C++ API (two std::threads for L/R,
-    SyncedMem::to_cpu x 4, ComputeStereoMatches) - tools/micro/frame_latency.cpp, built by __graft_entry__.build()."""
+    SyncedMem::to_cpu x 4, ComputeStereoMatches) - tools/micro/frame_latency.cpp, built by __graft_entry__.build().  left / right: a few
+    different pairs [n, H, W] that the driver rotates through (consecutive frames differ, as they do in a SLAM session)."""
     exe = os.path.join(ROOT, "tools", "micro", "frame_latency")
     if not os.path.exists(exe):
         return None
@@ -748,8 +781,9 @@ def measure_frame_latency(cfg, left, right, frames=300):
     H, W, L, tile, th, fx, bf = cfg
     with tempfile.TemporaryDirectory() as td:
         lp, rp = os.path.join(td, "l.raw"), os.path.join(td, "r.raw")
+        left = left if left.ndim == 3 else left[None]; right = right if right.ndim == 3 else right[None]
         left.tofile(lp); right.tofile(rp)
-        env = dict(os.environ, JSORB_JSON="1")
+        env = dict(os.environ, JSORB_JSON="1", JSORB_ROTATE_PAIRS=str(left.shape[0]))
         try:
             out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=env,
                                  capture_output=True, text=True, timeout=120)

@@ -50,14 +50,19 @@ namespace jsorb {
 #define DET_LIST_CAP 640
 #endif
 #define DET_LIST_STEP 256
+// waves per workgroup: they share the staged tile and take its region rows in turn
+#ifndef DET_NW
+#define DET_NW 4
+#endif
+#define DET_THREADS (64 * DET_NW)
 // compact form: survivor-list capacity of one wave (entries) and the capacity of its list of positives (u32 entries: score << 16 | ry << 8 | rx)
 #ifndef DET_CP_LIST_CAP
 #define DET_CP_LIST_CAP 384
 #endif
-// The positives of a workgroup share ONE pool: at least DET_POS_PERMILLE of the band's region pixels (a band is only as tall as that allows,
+// The positives of a workgroup share ONE pool in LDS: at least DET_POS_PERMILLE of the band's region pixels (a band is only as tall as that allows,
 // fill_detect_layout) and whatever else the LDS budget leaves; a test build caps it with DET_POS_MAX.  Positives on the benchmark images:
-// 3-7 % of the pixels on average, up to 18 % in single bands of the coarse levels (checker patches) - a pool that holds less sends bands through
-// k_detect_redo, which runs serially behind the launch (measured with per-wave lists of 192: 5 % of the bands redone, kernel + 30 %).
+// 3-7 % of the pixels on average, up to 18 % in single bands of the coarse levels (checker patches).  What does not fit spills into a chunk of
+// global memory (below), so a small pool costs a few L2 round trips in the dense bands, not a second pass.
 #define DET_POS_MIN 256
 #ifndef DET_POS_MAX
 #define DET_POS_MAX 8192
@@ -65,13 +70,17 @@ namespace jsorb {
 #ifndef DET_POS_PERMILLE
 #define DET_POS_PERMILLE 180
 #endif
-// LDS budget of a compact workgroup: 17 granules of 1280 B = 7 workgroups per CU (28 waves) and 9 granules left for another kernel's workgroup
-#define DET_CP_BUDGET (17 * 1280)
-// waves per workgroup: they share the staged tile and take its region rows in turn
-#ifndef DET_NW
-#define DET_NW 4
+// LDS budget of a compact workgroup in granules of 1280 B: 17 = 7 workgroups per CU (28 waves) and 9 granules left for another kernel's workgroup
+#ifndef DET_CP_GRANULES
+#define DET_CP_GRANULES 17
 #endif
-#define DET_THREADS (64 * DET_NW)
+#define DET_CP_BUDGET (DET_CP_GRANULES * 1280)
+// a spill chunk (u32 entries): a band's region has at most (4 * 64 + 2) x 130 pixels... bounded here by the LDS tile: 255 rows x 130 columns
+#define DET_SPILL_CHUNK (255 * 130)
+// spill chunks per image slot of a handle: a lane launch over m images has DET_SPILL_PER_IMAGE * m of them
+#ifndef DET_SPILL_PER_IMAGE
+#define DET_SPILL_PER_IMAGE 2
+#endif
 
 struct DetectLds {
     int img_stride;      // bytes per LDS image row (multiple of 16)
@@ -254,9 +263,13 @@ extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
 // k_detect_blur launch for single frames - both below)
 // CP: the compact form (see the head of the file); `redo` (CP only): the workgroup's band goes there if a wave's positives overflow -
 // redo[0] = number of listed bands, redo[2 + 2 i] = image, redo[3 + 2 i] = workgroup (k_detect_redo consumes and resets the list)
+// CP: the compact form (see the head of the file).  `redo` (CP only) is the lane's side-channel block: [0] bands listed for k_detect_redo,
+// [1] its workgroups that are done, [2] spill chunks handed out, [4 + 2 i], [5 + 2 i] = (image, workgroup) of listed band i; `spill`: the lane's arena of
+// spill chunks (DET_SPILL_CHUNK u32 entries each, n_spill of them).
 template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP, bool REDO = false>
 __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk, unsigned *redo = nullptr)
+                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk, unsigned *redo = nullptr,
+                                                 unsigned *spill = nullptr, int n_spill = 0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
@@ -270,16 +283,17 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const int lvl = (int)(wd & 15u), r = (int)((wd >> 4) & 0x3FFFu), grp = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
     const int H = lv.H, W = lv.W, th1 = lv.th, tw = lv.tw, R = lv.det_R;
-    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(lv.det_img_rows), "s"(H), "s"(th1), "s"(R));       // one round of loads
-    const int th = R * th1;               // rows of the band: R tile rows of th1 rows each (R = 1 on the levels with the largest tiles)
+    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(H), "s"(th1), "s"(R));       // one round of loads
     const int ktw = lv.k_tiles * tw;
     const int xg0 = grp * ktw;            // first image column of the tile group
-    const int y0 = r * th;                // first image row of the band
+    const int tr0 = r * R;                // first tile row of the band
+    const int th = R * th1;               // rows of the band: R tile rows of th1 rows each (R = 1 on the levels with the largest tiles)
+    const int y0 = tr0 * th1;             // first image row of the band
     DetectLds L;
     int flush_at;                                         // wave-uniform; INT_MAX when the list holds the worst case (no early ring test)
     static_assert(!(CP && REDO), "the redo pass runs the full-plane form");
     if constexpr (!REDO) {                                // the handle's own form: the host has laid it out (fill_detect_layout)
-        L.img_stride = DET_S; L.img_rows = lv.det_img_rows; L.score_w = lv.det_score_w; L.score_stride = lv.det_score_stride; L.score_rows = lv.det_score_rows; L.list_cap = lv.det_list_cap;
+        L.img_stride = DET_S; L.img_rows = th + 8; L.score_w = lv.det_score_w; L.score_stride = lv.det_score_stride; L.score_rows = th + 2; L.list_cap = lv.det_list_cap;      // (offsets and capacities of the whole band's layout serve a shorter pass as well)
         L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_pos = (size_t)lv.det_off_pos; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
         flush_at = lv.det_flush_at;
     } else {                                              // k_detect_redo on a compact handle: the full-plane layout of the same band (rare path: computed here)
@@ -290,7 +304,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     unsigned short *s_score = reinterpret_cast<unsigned short *>(smem + L.off_score);
     unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
     unsigned *s_pos = reinterpret_cast<unsigned *>(smem + L.off_pos);                              // CP: the workgroup's pool of positives
-    unsigned *s_overflow = reinterpret_cast<unsigned *>(smem + L.off_tree + (lv.tree_rank_ok ? 256 : 1024));      // CP: [0] != 0 - the positives did not fit the pool; [1] entries in the pool
+    unsigned *s_overflow = reinterpret_cast<unsigned *>(smem + L.off_tree + (lv.tree_rank_ok ? 256 : 1024));      // CP: [0] != 0 - no room for the band's positives (k_detect_redo takes it); [1] positives of the band; [2] the band's spill chunk (0: none)
     const int pos_cap = CP ? lv.det_pos_cap : 0;
     unsigned *s_colkey = reinterpret_cast<unsigned *>(smem + L.off_colkey);
     unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
@@ -327,7 +341,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             const int nsc = (L.score_w * L.score_rows * 2 + 15) >> 4;
             uint4 *z = reinterpret_cast<uint4 *>(s_score);
             for (int i = tid; i < nsc; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
-        } else if (tid < 2) s_overflow[tid] = 0u;
+        } else if (tid < 3) s_overflow[tid] = 0u;
         if (tid < 128) s_colkey[tid] = 0;
         if (lv.tree_rank_ok && tid < 64) reinterpret_cast<unsigned *>(s_tree)[tid] = lut_bits[ctab_tree(g) + 64 * lvl + tid];      // column priorities
     }
@@ -455,8 +469,32 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                     unsigned base = 0;
                     if (lane == 0) base = atomicAdd(s_overflow + 1, cnt);
                     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                    if (base + cnt > (unsigned)pos_cap) { dense = true; n_mine = 0; break; }      // the band is redone by k_detect_redo
-                    if (hit) (s_pos + base)[rank_in_chunk] = (sad << 16) | (unsigned)e;      // (a score is <= 16 * 255 = 4080)
+                    const unsigned ent = (sad << 16) | (unsigned)e;                     // (a score is <= 16 * 255 = 4080)
+                    if (base + cnt <= (unsigned)pos_cap) {
+                        if (hit) (s_pos + base)[rank_in_chunk] = ent;
+                    } else {
+                        // The pool is full: the entries beyond it SPILL into a chunk of global memory (L2) that the workgroup takes from the lane's arena the
+                        // first time it needs one - entry i of the band lives in the pool for i < pos_cap, else at chunk[i - pos_cap]; a chunk holds a whole
+                        // band's pixels, so it cannot run over.  One lane asks for the chunk; if two waves ask at the same time the loser's chunk is
+                        // simply left unused (the arena is reset with every launch).  Only when the arena is exhausted is the band listed for k_detect_redo.
+                        unsigned ch = 0;
+                        if (lane == 0) {
+                            ch = __hip_atomic_load(s_overflow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (ch == 0u) {
+                                const unsigned mine = atomicAdd(redo + 2, 1u) + 1u;                  // chunk ids from 1
+                                const unsigned old = atomicCAS(s_overflow + 2, 0u, mine);
+                                ch = old == 0u ? mine : old;
+                            }
+                        }
+                        ch = (unsigned)__builtin_amdgcn_readfirstlane((int)ch);
+                        if (ch > (unsigned)n_spill) { dense = true; n_mine = 0; break; }      // no chunk left: the band is redone by k_detect_redo
+                        unsigned *const chunk = spill + (size_t)(ch - 1u) * DET_SPILL_CHUNK;
+                        const unsigned idx = base + rank_in_chunk;
+                        if (hit) {
+                            if (idx < (unsigned)pos_cap) s_pos[idx] = ent;
+                            else chunk[idx - (unsigned)pos_cap] = ent;
+                        }
+                    }
                 }
             } else {
                 if (hit && !dense) (my_list + n_pos)[rank_in_chunk] = (unsigned short)e;
@@ -610,37 +648,33 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 #if defined(DET_KNOCKOUT) && (DET_KNOCKOUT == 2 || DET_KNOCKOUT == 3)
     if (tile_out) return;
 #endif
+    int n_all = 0;                                        // compact form: positives of the band (pool + spill chunk)
+    const unsigned *spill_chunk = nullptr;
     if constexpr (CP) {
-        // ---- compact form: a band with a wave that gave up is listed for k_detect_redo; otherwise the score plane is built now, where the image tile
-        // and the survivor lists were (every wave is past them) ----
+        // ---- compact form: a band that found no room for its positives is listed for k_detect_redo; otherwise the score plane is built now, where the
+        // image tile and the survivor lists were (every wave is past them) ----
+        n_all = (int)s_overflow[1];
+        if (n_all > pos_cap) spill_chunk = spill + (size_t)(s_overflow[2] - 1u) * DET_SPILL_CHUNK;
         if (s_overflow[0] != 0u) {                        // (one LDS word: the same for every thread of the workgroup)
             if (tid == 0) {
                 const unsigned slot = atomicAdd(redo, 1u);
-                redo[2 + 2 * slot] = (unsigned)b;
-                redo[3 + 2 * slot] = (unsigned)blk;
+                redo[4 + 2 * slot] = (unsigned)b;
+                redo[5 + 2 * slot] = (unsigned)blk;
             }
             return;
         }
-        // A wave zeroes the plane rows it owned in phase 1 (rows rbase .. rbase + rows_per_step - 1 of every DET_NW-th step, border steps included)
-        // and then scatters its own positives - which lie in exactly those rows - into them: LDS operations of one wave execute in order, so the
-        // only barrier needed is the one in front of the NMS, which reads the neighbours' rows.
+        // The whole workgroup zeroes the plane with 16-byte stores, a barrier, then thread i scatters entries i, i + 256, ... (pool, then spill chunk).
+        // (A form with one barrier less - every wave zeroes the rows it owned in phase 1 and scatters the entries of those rows - was slower: ~30 dword
+        // stores per lane instead of 4 wide ones, and every wave reads the whole pool: 110.5 k against 112.5 k pairs/s.)
         {
-            const int sstr = L.score_stride;              // even: a row is sstr / 2 dwords and starts on a dword
-            unsigned *const plane32 = reinterpret_cast<unsigned *>(s_score);
-            const int dw_per_step = (rows_per_step * sstr) >> 1;         // <= 130
-            for (int rbase = wave * rows_per_step; rbase < L.score_rows; rbase += DET_NW * rows_per_step) {
-                unsigned *const row = plane32 + ((rbase * sstr) >> 1);      // (two_rows: rbase is even; else one row of sstr / 2 dwords)
-                if (lane < dw_per_step) row[lane] = 0u;                      // (never beyond the wave's own rows: the next ones belong to a wave that may already be scattering)
-                if (lane + 64 < dw_per_step) row[lane + 64] = 0u;
-                if (lane + 128 < dw_per_step) row[lane + 128] = 0u;
-            }
-            // the pool holds the positives of all four waves in the order the chunks arrived: a wave takes the ones of ITS rows
-            const int n_all = (int)s_overflow[1];
-            const int own_sh = two_rows ? 1 : 0;
-            for (int i = lane; i < n_all; i += 64) {
-                const unsigned e = s_pos[i];
-                const unsigned ry = (e >> 8) & 255u;
-                if (((ry >> own_sh) & (DET_NW - 1)) == (unsigned)wave) s_score[__umul24(ry, (unsigned)sstr) + (e & 255u)] = (unsigned short)(e >> 16);
+            const int sstr = L.score_stride;
+            const int n16 = (sstr * ((L.score_rows + 1) & ~1) * 2 + 15) >> 4;
+            uint4 *z = reinterpret_cast<uint4 *>(s_score);
+            for (int i = tid; i < n16; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            for (int i = tid; i < n_all; i += DET_THREADS) {
+                const unsigned e = i < pos_cap ? s_pos[i] : spill_chunk[i - pos_cap];
+                s_score[__umul24((e >> 8) & 255u, (unsigned)sstr) + (e & 255u)] = (unsigned short)(e >> 16);
             }
         }
         __syncthreads();
@@ -680,9 +714,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         }
     };
     if constexpr (CP) {
-        const int n_all = (int)s_overflow[1];
-        for (int i = tid; i < n_all; i += DET_THREADS) {      // by pool index: every thread of the workgroup takes its share, whichever wave found the positive
-            const unsigned e = s_pos[i];
+        for (int i = tid; i < n_all; i += DET_THREADS) {      // by entry index: every thread of the workgroup takes its share, whichever wave found the positive
+            const unsigned e = i < pos_cap ? s_pos[i] : spill_chunk[i - pos_cap];
             nms_one((int)((e >> 8) & 255u), (int)(e & 255u), (int)(e >> 16));
         }
     } else if (!dense) {
@@ -709,7 +742,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         // ---- phase 4 (arg-max form): one thread per tile decodes the winner ----
         const int kt = lv.k_tiles;
         const int trow = (tid >= kt) + (tid >= 2 * kt) + (tid >= 3 * kt), tcol = tid - trow * kt;      // R <= 4 tile rows of kt tiles
-        const int tr = r * R + trow;                      // tile row in the level
+        const int tr = tr0 + trow;                        // tile row in the level
         if (tid < R * kt && tr < lv.nth && xg0 + tcol * tw < W) {
             const unsigned key = s_colkey[tid];
             const int sc = (int)(key >> 18);
@@ -769,7 +802,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                 gs = (gs - 1) / 2 + 1;
             }
             if (active && j == 0) {
-                const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tile;
+                const int tile_idx = tr0 * lv.ntw + grp * lv.k_tiles + tile;
                 tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] = ((unsigned long long)(unsigned)cur_sc << 32) | cur_lo;
             }
         }
@@ -807,39 +840,40 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         __syncthreads();
     }
     if (active && tile_loc == 0) {
-        const int tile_idx = r * lv.ntw + grp * lv.k_tiles + tile_in_grp;
+        const int tile_idx = tr0 * lv.ntw + grp * lv.k_tiles + tile_in_grp;
         tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] = cur;
     }
 }
 
 template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP>
 __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images, unsigned *redo)
+                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images, unsigned *redo, unsigned *spill, int n_spill)
 {
     // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
     // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
     asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
     int b, blk;
     if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
-    detect_workgroup<HAS_MASK, COMPASS, SWAR, CP>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk, redo);
+    detect_workgroup<HAS_MASK, COMPASS, SWAR, CP>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk, redo, spill, n_spill);
 }
 
-// Behind every compact launch: the bands whose positives did not fit a wave's list, through the full-plane form (whose waves fall back to a dense
-// scan of their rows, so it always finishes).  Normally redo[0] == 0 and the launch is a few hundred workgroups that read one word and leave.
-// The last workgroup to finish resets the list for the lane's next batch (redo[1] counts the workgroups that are done).
+// Behind every compact launch: the bands that found neither room in their pool nor a spill chunk (a whole batch of noise images), through the
+// full-plane form (whose waves fall back to a dense scan of their rows, so it always finishes).  Normally redo[0] == 0 and the launch is 64
+// workgroups that read one word and leave.  The last workgroup to finish resets the list and the spill arena for the lane's next batch
+// (redo[1] counts the workgroups that are done).
 template <bool HAS_MASK, bool COMPASS, bool SWAR>
 __global__ __launch_bounds__(DET_THREADS) void k_detect_redo(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
                                                      const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, unsigned *redo)
 {
     const unsigned n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-        const int b = (int)__builtin_amdgcn_readfirstlane(redo[2 + 2 * i]), blk = (int)__builtin_amdgcn_readfirstlane(redo[3 + 2 * i]);
+        const int b = (int)__builtin_amdgcn_readfirstlane(redo[4 + 2 * i]), blk = (int)__builtin_amdgcn_readfirstlane(redo[5 + 2 * i]);
         detect_workgroup<HAS_MASK, COMPASS, SWAR, false, true>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk);
         __syncthreads();                                  // the next band re-uses the LDS
     }
-    if (n != 0u && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0u; redo[1] = 0u; }      // every workgroup has read n and finished its bands
+        if (atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0u; redo[1] = 0u; redo[2] = 0u; }      // every workgroup has read n and finished its bands: list and spill arena are free again
     }
 }
 
@@ -864,21 +898,28 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect_blur(Geometry g, ImageSr
         else            { if (!g.lut_compass) LAUNCH(false, false, false); else if (g.det_swar_t4 > 0) LAUNCH(false, true, true); else LAUNCH(false, true, false); }     \
     } while (0)
 
-// redo: the lane's redo list (compact handles; 2 + 2 * n_images * detect_blocks words, zero before the first launch) - the redo pass follows on the same stream
+// redo: the lane's side-channel block (compact handles; detect_redo_words() per image slot, zero before the first launch); spill: the lane's arena
+// (detect_spill_bytes() per image slot) - the redo pass follows on the same stream
+size_t detect_redo_words(const Geometry &g) { return 4 + 2 * (size_t)g.detect_blocks; }
+size_t detect_spill_bytes() { return (size_t)DET_SPILL_PER_IMAGE * DET_SPILL_CHUNK * sizeof(unsigned); }
+size_t detect_spill_chunks_per_image() { return DET_SPILL_PER_IMAGE; }
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
-                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s, unsigned *redo, size_t redo_lds_bytes)
+                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s, unsigned *redo, size_t redo_lds_bytes, unsigned *spill)
 {
     if (g.det_compact) {
-#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, true>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, redo)
+        const int n_spill = DET_SPILL_PER_IMAGE * n_images;
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, true>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, redo, spill, n_spill)
         DETECT_DISPATCH(DETECT_LAUNCH);
 #undef DETECT_LAUNCH
+        static const bool no_redo = getenv("JSORB_EXPERIMENT_NO_REDO") != nullptr;      // timing experiment only (results are wrong as soon as a band needs the redo pass or the arena runs out)
+        if (no_redo) return;
         const long total = (long)g.detect_blocks * n_images;
-        const unsigned grid = (unsigned)std::min<long>(total, 256);
+        const unsigned grid = (unsigned)std::min<long>(total, 64);
 #define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect_redo<M, C, S>), dim3(grid), dim3(DET_THREADS), redo_lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, redo)
         DETECT_DISPATCH(DETECT_LAUNCH);
 #undef DETECT_LAUNCH
     } else {
-#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, false>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, (unsigned *)nullptr)
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, false>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, (unsigned *)nullptr, (unsigned *)nullptr, 0)
         DETECT_DISPATCH(DETECT_LAUNCH);
 #undef DETECT_LAUNCH
     }

@@ -25,7 +25,7 @@ TH_HIGH, TH_LOW = 100, 50   # ORBmatcher::TH_HIGH / TH_LOW, src/ORBmatcher.cpp:2
 KERNELS = ["k_pyramid", "k_detect", "k_compact", "k_blur", "k_describe", "k_stereo", "k_median", "k_nms_ms"]
 
 EXPORTS = [
-    "jsorb_create", "jsorb_destroy", "jsorb_last_error", "jsorb_version", "jsorb_extract", "jsorb_extract_into", "jsorb_extract_device",
+    "jsorb_create", "jsorb_destroy", "jsorb_last_error", "jsorb_version", "jsorb_plan_launch", "jsorb_extract", "jsorb_extract_into", "jsorb_extract_device",
     "jsorb_extract_batch_device_async", "jsorb_extract_batch_host_async", "jsorb_sync", "jsorb_n_images", "jsorb_n_keypoints",
     "jsorb_level_n_keypoints", "jsorb_keypoints_device", "jsorb_descriptors_device", "jsorb_copy_keypoints",
     "jsorb_copy_descriptors", "jsorb_n_levels", "jsorb_level_dims", "jsorb_level_tiles", "jsorb_total_tiles", "jsorb_scale",
@@ -80,6 +80,7 @@ def load_library(path=None):
         "jsorb_destroy": (None, [P]),
         "jsorb_last_error": (C.c_char_p, [P]),
         "jsorb_version": (C.c_char_p, []),
+        "jsorb_plan_launch": (I, [C.POINTER(JsorbParams), P, I]),
         "jsorb_extract": (I, [P, P, I, C.POINTER(I)]),
         "jsorb_extract_into": (I, [P, P, I, C.POINTER(I), P, P]),
         "jsorb_extract_device": (I, [P, P, I, C.POINTER(I)]),
@@ -152,6 +153,24 @@ def read_mask_image(path):
     if rc != 0:
         raise JsorbError("jsorb_read_mask_image rc=%d: %s" % (rc, lib.jsorb_mask_image_last_error().decode()))
     return out
+
+
+def plan_launch(im_height, im_width, scale_factor, n_levels, tile_h=30, tile_w=30, fixed_multi_scale_tile_size=False, max_batch=1,
+                FAST_N_MIN=9, FAST_N_MAX=14, th_FAST_MAX=20):
+    """jsorb_plan_launch: the launch plan of a handle with these parameters, computed on the host (no GPU needed).  Returns a dict with the
+    launch-wide numbers and a list of per-level dicts."""
+    lib = load_library()
+    prm = JsorbParams(im_height, im_width, n_levels, scale_factor, FAST_N_MIN, FAST_N_MAX, 7, th_FAST_MAX, tile_h, tile_w,
+                      int(fixed_multi_scale_tile_size), 0, 0, 0, max_batch)
+    out = np.zeros(8 + 8 * 16, np.int32)
+    rc = lib.jsorb_plan_launch(C.byref(prm), out.ctypes.data, out.size)
+    if rc != 0:
+        raise JsorbError("jsorb_plan_launch rc=%d" % rc)
+    keys = ("levels", "compact", "detect_lds", "redo_lds", "pyramid_lds", "detect_blocks", "spill_chunk_entries", "spill_chunks_per_image")
+    res = dict(zip(keys, (int(v) for v in out[:8])))
+    lk = ("det_R", "k_tiles", "pool", "score_stride", "list_cap", "pyr_ns16", "pyr_ns_dispatched", "tile_rows")
+    res["per_level"] = [dict(zip(lk, (int(v) for v in out[8 + 8 * i:16 + 8 * i]))) for i in range(res["levels"])]
+    return res
 
 
 class ORBExtractor:

@@ -1,5 +1,8 @@
 // Per-frame latency of the reference-shaped synchronous API from C++ (no Python in the loop): what Frame::Frame's stereo
 // constructor costs per frame.  Usage: frame_latency H W L tile th fx bf left.raw right.raw [frames]
+// The raw files may hold SEVERAL images back to back (JSORB_ROTATE_PAIRS=n reads n of them): frame k then works on pair k mod n, so that consecutive
+// frames differ - in soak mode (JSORB_CHECK_EVERY_FRAME=1) every frame is compared with what a SECOND pair of handles, which never arms the speculative
+// match, computed for its pair before the loop: a speculative match that delivered the previous frame's result would fail here (round-4 review).
 // Build: g++ -O2 -std=c++17 -I include tools/micro/frame_latency.cpp -L jetson_slam_amd -ljsorb -lpthread -Wl,-rpath,$PWD/jetson_slam_amd
 #include <algorithm>
 #include <atomic>
@@ -29,7 +32,9 @@ int main(int argc, char **argv)
     const int H = atoi(argv[1]), W = atoi(argv[2]), L = atoi(argv[3]), tile = atoi(argv[4]), th = atoi(argv[5]);
     const float fx = (float)atof(argv[6]), mbf = (float)atof(argv[7]);
     const int frames = argc > 10 ? atoi(argv[10]) : 300;
-    auto imL = read_raw(argv[8], (size_t)H * W), imR = read_raw(argv[9], (size_t)H * W);
+    const int n_pairs = getenv("JSORB_ROTATE_PAIRS") ? std::max(1, atoi(getenv("JSORB_ROTATE_PAIRS"))) : 1;
+    const size_t img_bytes = (size_t)H * W;
+    auto imL = read_raw(argv[8], img_bytes * n_pairs), imR = read_raw(argv[9], img_bytes * n_pairs);
     Jetson_SLAM::ORBExtractor exL(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
     Jetson_SLAM::ORBExtractor exR(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
     // The four SyncedMem members of a Frame (Frame.h:234-237).  Default: long-lived objects (what the reference's commented-out static
@@ -47,7 +52,7 @@ int main(int argc, char **argv)
     std::vector<unsigned char> desc, descR;
     const bool check_every = getenv("JSORB_CHECK_EVERY_FRAME") != nullptr;
     const bool persistent = getenv("JSORB_PERSISTENT_THREADS") != nullptr;
-    std::atomic<int> go{0}, done{0};
+    std::atomic<int> go{0}, done{0}, cur_pair{0};
     std::atomic<bool> quit{false};
     std::vector<std::thread> workers;
     if (persistent)
@@ -57,15 +62,36 @@ int main(int argc, char **argv)
                 for (;;) {
                     while (go.load(std::memory_order_acquire) == seen) { if (quit.load()) return; __builtin_ia32_pause(); }
                     seen++;
-                    if (side == 0) exL.extract(imL.data(), W, kpL, dL); else exR.extract(imR.data(), W, kpR, dR);
+                    const size_t off = img_bytes * (size_t)cur_pair.load(std::memory_order_relaxed);
+                    if (side == 0) exL.extract(imL.data() + off, W, kpL, dL); else exR.extract(imR.data() + off, W, kpR, dR);
                     done.fetch_add(1, std::memory_order_release);
                 }
             });
-    std::vector<float> u0, d0;
-    std::vector<jsorb_keypoint> k0;
+    // soak mode: the expected result of every pair from a second pair of handles through the plain C calls (no speculation is ever armed on them)
+    std::vector<std::vector<float>> u0(n_pairs), d0(n_pairs);
+    std::vector<std::vector<jsorb_keypoint>> k0(n_pairs);
+    if (check_every) {
+        Jetson_SLAM::ORBExtractor refL(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
+        Jetson_SLAM::ORBExtractor refR(H, W, 1.2f, L, 9, 14, 7, th, "", tile, tile, false, false, false, true);
+        for (int p = 0; p < n_pairs; p++) {
+            int nl = 0, nr = 0;
+            if (jsorb_extract(refL.handle(), imL.data() + img_bytes * p, W, &nl) != JSORB_OK || jsorb_extract(refR.handle(), imR.data() + img_bytes * p, W, &nr) != JSORB_OK) return 5;
+            u0[p].assign(nl, 0.f); d0[p].assign(nl, 0.f);
+            jsorb_stereo_stats st;
+            if (jsorb_stereo_match(refL.handle(), refR.handle(), mbf / fx, mbf, 100, 50, u0[p].data(), d0[p].data(), &st) != JSORB_OK) return 5;
+            std::vector<unsigned char> dd;
+            Jetson_SLAM::UnpackFrame(refL, k0[p], dd);
+        }
+        long a = 0, dr = 0;
+        jsorb_speculative_stereo_stats(refL.handle(), &a, &dr);
+        if (a != 0) { fprintf(stderr, "the reference handles adopted a speculative match\n"); return 5; }
+    }
     double t_ext = 0, t_cpu = 0, t_st = 0, t_unp = 0;
     std::vector<double> per_frame;
     for (int it = -20; it < frames; it++) {
+        const int pair = (it + 20) % n_pairs;
+        const size_t off = img_bytes * (size_t)pair;
+        cur_pair.store(pair, std::memory_order_relaxed);
         const double t0 = now_us();
         if (fresh) mems.reset(new FrameMems);         // inside the timed region: it is part of what a frame costs
         if (persistent) {        // what an integrator gains by keeping the two extractor threads alive (not the reference's code shape)
@@ -73,8 +99,8 @@ int main(int argc, char **argv)
             go.fetch_add(1, std::memory_order_release);
             while (done.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
         } else {
-            std::thread tl([&] { exL.extract(imL.data(), W, kpL, dL); });   // Frame.cpp:107-110
-            std::thread tr([&] { exR.extract(imR.data(), W, kpR, dR); });
+            std::thread tl([&] { exL.extract(imL.data() + off, W, kpL, dL); });   // Frame.cpp:107-110
+            std::thread tr([&] { exR.extract(imR.data() + off, W, kpR, dR); });
             tl.join(); tr.join();
         }
         const double t1 = now_us();
@@ -84,11 +110,12 @@ int main(int argc, char **argv)
         const double t3 = now_us();
         Jetson_SLAM::UnpackFrame(exL, keys, desc); Jetson_SLAM::UnpackFrame(exR, keysR, descR);      // alternative to the four to_cpu()
         const double t4 = now_us();
-        if (check_every) {       // soak mode: the input never changes, so every frame must reproduce the first one bit for bit
-            if (it == -20) { u0 = mvuRight; d0 = mvDepth; k0 = keys; }
-            else if (u0.size() != mvuRight.size() || memcmp(u0.data(), mvuRight.data(), u0.size() * 4) || memcmp(d0.data(), mvDepth.data(), d0.size() * 4) ||
-                     k0.size() != keys.size() || memcmp(k0.data(), keys.data(), k0.size() * sizeof(jsorb_keypoint))) {
-                fprintf(stderr, "frame %d differs from the first frame\n", it);
+        if (check_every) {       // soak mode: every frame must reproduce, bit for bit, what the plain path computed for ITS pair
+            const std::vector<float> &ue = u0[pair], &de = d0[pair];
+            const std::vector<jsorb_keypoint> &ke = k0[pair];
+            if (ue.size() != mvuRight.size() || memcmp(ue.data(), mvuRight.data(), ue.size() * 4) || memcmp(de.data(), mvDepth.data(), de.size() * 4) ||
+                ke.size() != keys.size() || memcmp(ke.data(), keys.data(), ke.size() * sizeof(jsorb_keypoint))) {
+                fprintf(stderr, "frame %d (pair %d) differs from the plain path's result for that pair\n", it, pair);
                 return 4;
             }
         }
@@ -102,7 +129,10 @@ int main(int argc, char **argv)
     jsorb_speculative_stereo_stats(exL.handle(), &adopted, &dropped);
     std::vector<float> u_spec = mvuRight, d_spec = mvDepth, u_ref, d_ref;
     jsorb_set_speculative_stereo(exL.handle(), 0);
-    exL.extract(imL.data(), W, kpL, dL); exR.extract(imR.data(), W, kpR, dR);
+    {
+        const size_t off = img_bytes * (size_t)((frames - 1 + 20) % n_pairs);      // the last frame's pair
+        exL.extract(imL.data() + off, W, kpL, dL); exR.extract(imR.data() + off, W, kpR, dR);
+    }
     Jetson_SLAM::ComputeStereoMatches(exL, exR, mbf / fx, mbf, u_ref, d_ref);
     const bool same = u_ref.size() == u_spec.size() && d_ref.size() == d_spec.size() && !u_ref.empty() &&
                       memcmp(u_ref.data(), u_spec.data(), u_ref.size() * sizeof(float)) == 0 && memcmp(d_ref.data(), d_spec.data(), d_ref.size() * sizeof(float)) == 0;
@@ -110,8 +140,8 @@ int main(int argc, char **argv)
     std::sort(per_frame.begin(), per_frame.end());
     const double med = per_frame.empty() ? 0.0 : per_frame[per_frame.size() / 2], p90 = per_frame.empty() ? 0.0 : per_frame[per_frame.size() * 9 / 10];
     if (getenv("JSORB_JSON"))
-        printf("{\"frames\": %d, \"total_us_median\": %.1f, \"total_us_p90\": %.1f, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
-               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames, med, p90,
+        printf("{\"frames\": %d, \"pairs_rotated\": %d, \"total_us_median\": %.1f, \"total_us_p90\": %.1f, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
+               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames, n_pairs, med, p90,
                t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped);
     else
     printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f ; "
