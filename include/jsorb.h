@@ -76,8 +76,8 @@ const char *jsorb_last_error(const jsorb_extractor *e);
 const char *jsorb_version(void);
 /* Host-only, touches no device: the launch plan a handle created with these parameters gets (no counterpart in the reference, whose launch shapes
  * are literals in its .cu files, e.g. src/cuda/orb_FAST_apply_NMS_G.cu:1405-1434).  out[0..7] = levels, k_detect form (1: compact, 0: full plane),
- * k_detect LDS bytes, k_detect_redo LDS bytes, k_pyramid LDS bytes, k_detect workgroups per image, entries per spill chunk, spill chunks per image
- * slot; then 8 ints per level: tile rows per k_detect workgroup, tiles per workgroup, LDS pool entries, score-plane stride, survivor-list capacity,
+ * k_detect LDS bytes, spill chunks in the handle's arena, k_pyramid LDS bytes, k_detect workgroups per image, entries per spill chunk, 0 (reserved);
+ * then 8 ints per level: tile rows per k_detect workgroup, tiles per workgroup, LDS pool entries, score-plane stride, survivor-list capacity,
  * 16-byte loads per lane and row of k_pyramid, the load count its kernel instantiates for that, tile rows of the level.  capacity >= 8 + 8 * levels. */
 int jsorb_plan_launch(const jsorb_params *params, int32_t *out, int capacity);
 

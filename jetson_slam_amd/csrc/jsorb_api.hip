@@ -105,9 +105,7 @@ struct jsorb_extractor {
     bool main_stream_dirty = false;    // this call enqueued input copies on the main stream: the lanes must fork after them
     bool counts_synced = false;        // h_counts / h_stats reflect the last enqueued batch (set by jsorb_sync)
     size_t detect_lds = 0, pyr_lds = 0;
-    size_t detect_redo_lds = 0;        // compact k_detect: dynamic LDS of k_detect_redo
-    unsigned *det_redo = nullptr;      // compact k_detect: side-channel blocks (counters + redo list), detect_redo_words() per image slot - a lane launch over images [f, f + m) uses the words of its slots, counters first; zero between launches
-    unsigned *det_spill = nullptr;     // compact k_detect: spill arena, detect_spill_bytes() per image slot (positives beyond a workgroup's LDS pool)
+    unsigned *det_spill = nullptr, *det_spill_flags = nullptr;      // compact k_detect: arena of spill chunks (positives beyond a workgroup's LDS pool) and one busy flag per chunk
     // device buffers
     uint8_t *slab = nullptr, *blur = nullptr, *mask = nullptr;
     // host uploads: two dense B x H0 x W0 landing buffers filled by ONE hipMemcpyAsync per batch on a dedicated copy stream, then read
@@ -657,9 +655,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         static const bool fuse_env = !(getenv("JSORB_FUSED_DETECT_BLUR") && atoi(getenv("JSORB_FUSED_DETECT_BLUR")) == 0);
         const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0 && !g.det_compact && e->detect_lds + 12 * 1024 <= 64 * 1024;      // (k_blur's 10 KB of static LDS come on top of k_detect's request)
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
-        else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st,
-                                                       e->det_redo ? e->det_redo + (size_t)f * detect_redo_words(g) : nullptr, e->detect_redo_lds,
-                                                       e->det_spill ? e->det_spill + (size_t)f * (detect_spill_bytes() / sizeof(unsigned)) : nullptr));
+        else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st, e->det_spill, e->det_spill_flags));
         if (e->nms_ms)
             JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
                                                       e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
@@ -855,7 +851,7 @@ static void plan_detect(Geometry &g)
 
 /* Host-only (no device is touched): the launch plan a handle with these parameters gets - what tests/test_round5_host_logic.py checks the LDS
  * layouts against.  out[0..7] = levels, compact form (0 / 1), k_detect LDS bytes (before jsorb_create's per-CU partition adjustment of the full-plane
- * form), k_detect_redo LDS bytes, k_pyramid LDS bytes, k_detect workgroups per image, entries of a spill chunk, spill chunks per image slot; then 8 ints
+ * form), spill chunks in the handle's arena, k_pyramid LDS bytes, k_detect workgroups per image, entries of a spill chunk, 0; then 8 ints
  * per level: det_R, k_tiles, pool entries, score-plane stride, survivor-list capacity, pyr_ns16, the NS k_pyramid instantiates for it, tile rows. */
 int jsorb_plan_launch(const jsorb_params *params, int32_t *out, int capacity)
 {
@@ -866,8 +862,8 @@ int jsorb_plan_launch(const jsorb_params *params, int32_t *out, int capacity)
     if (rc) return rc;
     plan_detect(g);
     if (capacity < 8 + 8 * g.L) return JSORB_ERR_INVALID;
-    out[0] = g.L; out[1] = g.det_compact; out[2] = (int32_t)detect_lds_bytes(g); out[3] = g.det_compact ? (int32_t)detect_redo_lds_bytes(g) : 0;
-    out[4] = (int32_t)pyramid_lds_bytes(g); out[5] = g.detect_blocks; out[6] = (int32_t)(detect_spill_bytes() / 4 / std::max<size_t>(1, detect_spill_chunks_per_image())); out[7] = (int32_t)detect_spill_chunks_per_image();
+    out[0] = g.L; out[1] = g.det_compact; out[2] = (int32_t)detect_lds_bytes(g); out[3] = g.det_compact ? (int32_t)detect_arena_flag_words() : 0;
+    out[4] = (int32_t)pyramid_lds_bytes(g); out[5] = g.detect_blocks; out[6] = g.det_compact ? detect_spill_chunk_entries(g) : 0; out[7] = 0;
     for (int i = 0; i < g.L; i++) {
         int32_t *o = out + 8 + 8 * i;
         o[0] = g.lv[i].det_R; o[1] = g.lv[i].k_tiles; o[2] = g.det_compact ? g.lv[i].det_pos_cap : 0; o[3] = g.lv[i].det_score_stride;
@@ -912,8 +908,7 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     if (const char *mp = getenv("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
     plan_detect(g);
     e->detect_lds = detect_lds_bytes(g);
-    e->detect_redo_lds = g.det_compact ? detect_redo_lds_bytes(g) : 0;
-    if (e->detect_lds > 160 * 1024 || e->detect_redo_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
+    if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
     // LDS partition of a CU in the batch pipeline (profiles/r04_lds_counters.txt, "LDS request sweep"): the lanes overlap k_detect of one image
     // group with k_describe of another, and what decides whether a k_describe workgroup can start on a CU that k_detect fills is LDS, which
     // is handed out in 1280-byte granules.  The request is therefore raised to the largest one that still lets four k_detect workgroups AND
@@ -950,10 +945,9 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     if (g.det_compact) {
-        const size_t n = B * detect_redo_words(g) * sizeof(unsigned);
-        HIPCHK(e, hipMalloc(&e->det_redo, n));
-        HIPCHK(e, hipMemset(e->det_redo, 0, n));
-        HIPCHK(e, hipMalloc(&e->det_spill, std::max<size_t>(B * detect_spill_bytes(), 256)));
+        HIPCHK(e, hipMalloc(&e->det_spill, detect_arena_bytes(g)));
+        HIPCHK(e, hipMalloc(&e->det_spill_flags, detect_arena_flag_words() * sizeof(unsigned)));
+        HIPCHK(e, hipMemset(e->det_spill_flags, 0, detect_arena_flag_words() * sizeof(unsigned)));
     }
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
     HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
@@ -1068,7 +1062,7 @@ void jsorb_destroy(jsorb_extractor *e)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->det_redo, e->det_spill, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
+                    e->out_kp, e->det_spill, e->det_spill_flags, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_counts) (void)hipHostFree(e->h_counts);

@@ -31,11 +31,10 @@ int detect_ring_bit_of_pixel(int k);       // bit of ring pixel k in the index o
 void fill_detect_layout(Geometry &g);      // tile rows per workgroup (det_R), workgroup table offsets and per-level LDS layout of k_detect (host side, once per handle)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s,
-                   unsigned *redo = nullptr, size_t redo_lds_bytes = 0, unsigned *spill = nullptr);      // compact handles: k_detect (compact form) + k_detect_redo on the lane's side-channel block
-size_t detect_redo_words(const Geometry &g);   // u32 words of side-channel block per image slot (counters + redo list)
-size_t detect_spill_chunks_per_image();
-size_t detect_spill_bytes();               // bytes of spill arena per image slot (positives that do not fit a workgroup's LDS pool)
-size_t detect_redo_lds_bytes(const Geometry &g);   // dynamic LDS of k_detect_redo (the full-plane form on the compact handle's bands)
+                   unsigned *spill = nullptr, unsigned *spill_flags = nullptr);      // compact handles: the arena of spill chunks and its busy flags
+int detect_spill_chunk_entries(const Geometry &g);      // u32 entries of one spill chunk (the handle's largest band region)
+size_t detect_arena_bytes(const Geometry &g);           // the whole arena: 8 XCDs x slots x chunk
+size_t detect_arena_flag_words();                       // one busy flag per chunk
 int detect_pos_cap(const Geometry &g, int level);   // entries of a k_detect workgroup's pool of positives on that level (compact form)
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,

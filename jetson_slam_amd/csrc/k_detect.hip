@@ -26,13 +26,13 @@
 // 4-wave workgroup = 4 waves per SIMD, half of a wave's life spent waiting), and 260 of the ~420 LDS bytes a band row costs were the u16 score
 // plane, >= 93 % zeros, alive from phase 0 on.  In the compact form a positive's score travels in its list entry (score << 16 | row << 8 | column, a
 // workgroup-wide u32 pool filled with one LDS atomic per ring-test chunk), and the plane is built only when phases 1 + 2 are over - ON TOP of the
-// image tile and the survivor lists, which are dead by then: every wave zeroes the plane rows it owned in phase 1 and scatters the pool's positives of
-// THOSE rows into them, one more barrier, then the NMS reads the plane as before (its work spread over all 256 threads by pool index).  20 KB
-// instead of 33 KB at the SAME band heights = 8 workgroups per CU (timing-only knock-out first: -27 % kernel time,
-// profiles/r05_detect_occupancy_knockout.txt).  The pool takes what the 20 KB leave (~1000 entries: 13 % of a band's pixels; the benchmark
-// images have 3-7 % positives, with single waves at 3 x the mean - per-wave lists of 192 overflowed in a third of the bands).  A band whose
-// positives do not fit cannot fall back to a dense scan - there is no plane to scan - so the workgroup hands it to a redo list, and
-// k_detect_redo, launched behind every compact launch, runs the listed bands through the full-plane form (normally: reads a zero counter and exits).
+// image tile and the survivor lists, which are dead by then: the workgroup zeroes the plane, scatters the pool into it, and the NMS reads the plane
+// as before (its work spread over all 256 threads by pool index).  21 KB instead of 33 KB at the SAME band heights = 7 workgroups per CU
+// (timing-only knock-out first: -27 % kernel time, profiles/r05_detect_occupancy_knockout.txt).  The benchmark images have 3-7 % positives on average
+// and up to 18 % in single bands (checker patches on the coarse levels); the pool holds >= 10 % of a band's pixels, and what does not fit SPILLS into a
+// chunk of global memory the workgroup borrows from the handle's arena: entry i of a band lives in the pool for i < pos_cap, else at chunk[i - pos_cap].
+// The arena has a chunk for every workgroup that can be resident (per XCD: claimed with a compare-and-swap on a flag, returned at the end), and a
+// chunk holds a whole band's pixels - so the compact form needs no second pass and no fallback: an image of pure noise costs L2 round trips, nothing else.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -68,18 +68,22 @@ namespace jsorb {
 #define DET_POS_MAX 8192
 #endif
 #ifndef DET_POS_PERMILLE
-#define DET_POS_PERMILLE 180
+#define DET_POS_PERMILLE 100
 #endif
-// LDS budget of a compact workgroup in granules of 1280 B: 17 = 7 workgroups per CU (28 waves) and 9 granules left for another kernel's workgroup
+// LDS budget of a compact workgroup in granules of 1280 B: 18 = 7 workgroups per CU (28 waves).  Measured (C2, pairs/s of the 4-lane pipeline /
+// k_detect ms per step, full-plane form 121.3 k / 0.538 on that box; tools/micro/r5_exp9.sh): 17 granules with a pool of >= 18 % of the band's
+// pixels 119.0 k / 0.419, 18 / 18 % 119.4 k / 0.416, 17 / 10 % (level 1 gets a third tile row per band: 202 instead of 220 workgroups per image)
+// 118.4 k / 0.419, 18 / 10 % 120.5 k / 0.411, 19 / 10 % (6 workgroups per CU) 119.4 k / 0.440, 17 / 6 % 119.0 k / 0.415.
 #ifndef DET_CP_GRANULES
-#define DET_CP_GRANULES 17
+#define DET_CP_GRANULES 18
 #endif
 #define DET_CP_BUDGET (DET_CP_GRANULES * 1280)
-// a spill chunk (u32 entries): a band's region has at most (4 * 64 + 2) x 130 pixels... bounded here by the LDS tile: 255 rows x 130 columns
-#define DET_SPILL_CHUNK (255 * 130)
-// spill chunks per image slot of a handle: a lane launch over m images has DET_SPILL_PER_IMAGE * m of them
-#ifndef DET_SPILL_PER_IMAGE
-#define DET_SPILL_PER_IMAGE 2
+// The spill arena of a handle: 8 XCDs x DET_ARENA_SLOTS chunks.  A workgroup only ever touches the chunks of the XCD it runs on (s_getreg XCC_ID), so a
+// chunk's data passes through ONE L2 - the L2s of different XCDs are not coherent with each other inside a kernel.  At most 32 CUs x 8 workgroups of
+// this kernel are resident per XCD (4 waves each, 32 wave slots per CU): 320 slots can never all be taken.
+#define DET_ARENA_XCDS 8
+#ifndef DET_ARENA_SLOTS
+#define DET_ARENA_SLOTS 320
 #endif
 
 struct DetectLds {
@@ -107,8 +111,8 @@ __host__ __device__ inline DetectLds detect_lds_layout(int th, int tw, int k_til
     // a wave owns <= 2*ceil(rows/8) rows of the score region.  The list is CAPPED (the worst case - every pixel survives the early
     // rejects - would cost 7.8 KB at tile 30 and hold the kernel at 7 workgroups per CU): when a wave's list could not take another
     // early-reject step (DET_LIST_STEP entries), the wave runs its ring test on what it has - only positives stay in the list - and
-    // goes on; if even the positives do not fit, the wave falls back to a dense scan of its rows in phase 3 (full-plane form) or hands
-    // the band to the redo list (compact form).
+    // goes on; if even the positives do not fit, the wave falls back to a dense scan of its rows in phase 3 (full-plane form; in the compact
+    // form positives never stay in this list).
     const int full = 2 * ((d.score_rows + 2 * DET_NW - 1) / (2 * DET_NW)) * d.score_w;
     const int cap = compact ? DET_CP_LIST_CAP : DET_LIST_CAP;
     d.list_cap = full <= cap ? full : cap;
@@ -170,7 +174,7 @@ void fill_detect_layout(Geometry &g)
     // prologue of ~230 scalar + ~150 vector instructions, and the scalar pipe is nearly as busy as the vector pipes in this kernel.  Measured at the
     // end of round 3 (pairs/s at C2 / C3 / C5): 7 workgroups per CU (the round-2 choice) 107.1 / 80.6 / 30.8 k, 6: 109.7 / 84.9 / 31.7 k,
     // 5: 111.7 / 85.5 / 32.0-32.3 k, 4: 109.5 / 85.7 / 31.6 k.
-    // Compact form (round 5): the same band heights cost ~21 KB with a pool for 18 % positives: the budget is 17 granules - 7 workgroups = 7 waves per SIMD.
+    // Compact form (round 5): the same band heights cost ~22 KB with a pool for >= 10 % positives: the budget is 18 granules - 7 workgroups = 7 waves per SIMD.
     if (const char *b7 = getenv("JSORB_DETECT_BUDGET")) budget = std::max(budget, (size_t)atoi(b7));
     else budget = std::max(budget, cp ? (size_t)DET_CP_BUDGET : (size_t)(160 * 1024 / 5 - 256));
     int dblk = 0;
@@ -193,7 +197,7 @@ void fill_detect_layout(Geometry &g)
     g.detect_blocks = dblk;
 }
 
-// dynamic LDS of the primary launch (the handle's form) and of the redo launch (the full-plane form on the SAME bands)
+// dynamic LDS of the launch (the handle's form)
 static size_t detect_lds_bytes_form(const Geometry &g, int compact)
 {
     size_t m = 0;
@@ -205,7 +209,15 @@ static size_t detect_lds_bytes_form(const Geometry &g, int compact)
     return m;
 }
 size_t detect_lds_bytes(const Geometry &g) { return detect_lds_bytes_form(g, g.det_compact); }
-size_t detect_redo_lds_bytes(const Geometry &g) { return detect_lds_bytes_form(g, 0); }
+// entries of one spill chunk: the largest band region of the handle (every pixel a positive)
+int detect_spill_chunk_entries(const Geometry &g)
+{
+    int m = 1;
+    for (int i = 0; i < g.L; i++) m = std::max(m, g.lv[i].det_score_w * g.lv[i].det_score_rows);
+    return (m + 63) & ~63;
+}
+size_t detect_arena_bytes(const Geometry &g) { return (size_t)DET_ARENA_XCDS * DET_ARENA_SLOTS * detect_spill_chunk_entries(g) * sizeof(unsigned); }
+size_t detect_arena_flag_words() { return (size_t)DET_ARENA_XCDS * DET_ARENA_SLOTS; }
 int detect_pos_cap(const Geometry &g, int level) { return g.lv[level].det_pos_cap; }
 
 // Early rejects on 6-bit pixels (k_detect phase 1, SWAR form): with q(x) = x >> 2 and t4 = (th + 1) >> 2,
@@ -261,15 +273,35 @@ extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
 
 // one workgroup of k_detect: image b, workgroup blk of the image's g.detect_blocks (a kernel of its own for batches, one half of the fused
 // k_detect_blur launch for single frames - both below)
-// CP: the compact form (see the head of the file); `redo` (CP only): the workgroup's band goes there if a wave's positives overflow -
-// redo[0] = number of listed bands, redo[2 + 2 i] = image, redo[3 + 2 i] = workgroup (k_detect_redo consumes and resets the list)
-// CP: the compact form (see the head of the file).  `redo` (CP only) is the lane's side-channel block: [0] bands listed for k_detect_redo,
-// [1] its workgroups that are done, [2] spill chunks handed out, [4 + 2 i], [5 + 2 i] = (image, workgroup) of listed band i; `spill`: the lane's arena of
-// spill chunks (DET_SPILL_CHUNK u32 entries each, n_spill of them).
-template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP, bool REDO = false>
+// A workgroup's first spill: claim a free chunk of the XCD the wave runs on (compare-and-swap on the chunk's busy flag, probing from a slot that depends
+// on the workgroup), publish it in the workgroup's LDS word; if another wave of the workgroup was faster, give the chunk back and take that one.
+// Returns chunk index + 1.  Deliberately NOT inlined: the probing loop sits in the middle of the ring pass, where the scalar registers are scarce -
+// inlined, the kernel went from 82 to 106 SGPRs and its hot loops reloaded kernel arguments (k_detect 215 -> 247 us per 128 images).
+__device__ __attribute__((noinline)) unsigned detect_claim_chunk(unsigned *spill_flags, unsigned *s_chunk, unsigned blk, unsigned b)
+{
+    unsigned ch = __hip_atomic_load(s_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ch != 0u) return ch;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & (DET_ARENA_XCDS - 1);      // HW_REG_XCC_ID[3:0]
+    unsigned *const fl = spill_flags + xcc * DET_ARENA_SLOTS;
+    unsigned slot = (blk * 2654435761u + b * 40503u) % DET_ARENA_SLOTS;
+    int tries = 0;
+#pragma clang loop unroll(disable)
+    while (atomicCAS(fl + slot, 0u, 1u) != 0u) {
+        slot = slot + 1 == DET_ARENA_SLOTS ? 0 : slot + 1;
+        if (++tries > 8 * DET_ARENA_SLOTS) __builtin_trap();      // cannot happen (more slots than resident workgroups): fail loudly rather than hang
+    }
+    const unsigned mine = xcc * DET_ARENA_SLOTS + slot + 1u;
+    const unsigned old = atomicCAS(s_chunk, 0u, mine);
+    if (old == 0u) return mine;
+    __hip_atomic_store(fl + slot, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return old;
+}
+
+// CP: the compact form (see the head of the file); spill / spill_flags / chunk_entries: the handle's arena of spill chunks (CP only)
+template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP>
 __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk, unsigned *redo = nullptr,
-                                                 unsigned *spill = nullptr, int n_spill = 0)
+                                                 const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int b, int blk,
+                                                 unsigned *spill = nullptr, unsigned *spill_flags = nullptr, int chunk_entries = 0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
@@ -283,7 +315,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const int lvl = (int)(wd & 15u), r = (int)((wd >> 4) & 0x3FFFu), grp = (int)(wd >> 18);
     const LevelDesc &lv = g.lv[lvl];
     const int H = lv.H, W = lv.W, th1 = lv.th, tw = lv.tw, R = lv.det_R;
-    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(H), "s"(th1), "s"(R));       // one round of loads
+    asm volatile("" ::"s"(lv.img_off), "s"(lv.pitch), "s"(lv.k_tiles), "s"(lv.det_img_rows), "s"(H), "s"(th1), "s"(R));       // one round of loads
     const int ktw = lv.k_tiles * tw;
     const int xg0 = grp * ktw;            // first image column of the tile group
     const int tr0 = r * R;                // first tile row of the band
@@ -291,20 +323,14 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const int y0 = tr0 * th1;             // first image row of the band
     DetectLds L;
     int flush_at;                                         // wave-uniform; INT_MAX when the list holds the worst case (no early ring test)
-    static_assert(!(CP && REDO), "the redo pass runs the full-plane form");
-    if constexpr (!REDO) {                                // the handle's own form: the host has laid it out (fill_detect_layout)
-        L.img_stride = DET_S; L.img_rows = th + 8; L.score_w = lv.det_score_w; L.score_stride = lv.det_score_stride; L.score_rows = th + 2; L.list_cap = lv.det_list_cap;      // (offsets and capacities of the whole band's layout serve a shorter pass as well)
-        L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_pos = (size_t)lv.det_off_pos; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
-        flush_at = lv.det_flush_at;
-    } else {                                              // k_detect_redo on a compact handle: the full-plane layout of the same band (rare path: computed here)
-        L = detect_lds_layout(R * th1, lv.tw, lv.k_tiles, lv.tree_rank_ok, 0);
-        flush_at = detect_flush_at(L);
-    }
+    L.img_stride = DET_S; L.img_rows = lv.det_img_rows; L.score_w = lv.det_score_w; L.score_stride = lv.det_score_stride; L.score_rows = lv.det_score_rows; L.list_cap = lv.det_list_cap;
+    L.off_score = (size_t)lv.det_off_score; L.off_list = (size_t)lv.det_off_list; L.off_pos = (size_t)lv.det_off_pos; L.off_colkey = (size_t)lv.det_off_colkey; L.off_tree = (size_t)lv.det_off_tree;
+    flush_at = lv.det_flush_at;
     unsigned char *s_img = smem;
     unsigned short *s_score = reinterpret_cast<unsigned short *>(smem + L.off_score);
     unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + L.off_list);
     unsigned *s_pos = reinterpret_cast<unsigned *>(smem + L.off_pos);                              // CP: the workgroup's pool of positives
-    unsigned *s_overflow = reinterpret_cast<unsigned *>(smem + L.off_tree + (lv.tree_rank_ok ? 256 : 1024));      // CP: [0] != 0 - no room for the band's positives (k_detect_redo takes it); [1] positives of the band; [2] the band's spill chunk (0: none)
+    unsigned *s_overflow = reinterpret_cast<unsigned *>(smem + L.off_tree + (lv.tree_rank_ok ? 256 : 1024));      // CP: [1] positives of the band; [2] the band's spill chunk + 1 (0: none)
     const int pos_cap = CP ? lv.det_pos_cap : 0;
     unsigned *s_colkey = reinterpret_cast<unsigned *>(smem + L.off_colkey);
     unsigned long long *s_tree = reinterpret_cast<unsigned long long *>(smem + L.off_tree);
@@ -395,7 +421,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const int e_lane = (sub << 8) + (cb - c0);                                           // list entry of the lane's first pixel in row `sub`
     const int min_pop = g.lut_min_pop;
     int n_pos = 0;                                        // wave-uniform: positives at the front of the list
-    bool dense = false;                                   // wave-uniform: the positives overflowed - full-plane form: phase 3 scans this wave's rows densely; compact form: the band goes to the redo list
+    bool dense = false;                                   // wave-uniform, full-plane form: the positives overflowed the list, phase 3 scans this wave's rows densely
     // ---- phase 2 (called when the list could not take another early-reject step, and once at the end): full 16-ring test + score,
     // each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
@@ -405,7 +431,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 #endif
     // Compact form: the pending survivors are the whole list [0, n_mine); a pass takes full chunks of 64 from its END (the order of the entries is
     // free) and leaves the < 64 others pending unless it is the wave's last pass, so every ring test but the last one runs on a full wave; a positive goes
-    // to the wave's list of positives with its score.  When that list could not take another chunk the wave gives up: the band goes to the redo list.
+    // to the workgroup's pool of positives (or its spill chunk) with its score.
     auto ring_pass = [&](bool last) {
         DET_T(t_r0);
         (void)last;
@@ -470,30 +496,19 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                     if (lane == 0) base = atomicAdd(s_overflow + 1, cnt);
                     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                     const unsigned ent = (sad << 16) | (unsigned)e;                     // (a score is <= 16 * 255 = 4080)
-                    if (base + cnt <= (unsigned)pos_cap) {
+                    if (__builtin_expect(base + cnt <= (unsigned)pos_cap, 1)) {
                         if (hit) (s_pos + base)[rank_in_chunk] = ent;
                     } else {
-                        // The pool is full: the entries beyond it SPILL into a chunk of global memory (L2) that the workgroup takes from the lane's arena the
-                        // first time it needs one - entry i of the band lives in the pool for i < pos_cap, else at chunk[i - pos_cap]; a chunk holds a whole
-                        // band's pixels, so it cannot run over.  One lane asks for the chunk; if two waves ask at the same time the loser's chunk is
-                        // simply left unused (the arena is reset with every launch).  Only when the arena is exhausted is the band listed for k_detect_redo.
+                        // The pool is full: the entries beyond it SPILL into a chunk of global memory that the workgroup borrows from the handle's arena the
+                        // first time it needs one.  One lane claims a free chunk of ITS XCD (compare-and-swap on the chunk's flag, probing from a
+                        // slot that depends on the workgroup); if two waves claim at the same time the loser gives its chunk back.
                         unsigned ch = 0;
-                        if (lane == 0) {
-                            ch = __hip_atomic_load(s_overflow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (ch == 0u) {
-                                const unsigned mine = atomicAdd(redo + 2, 1u) + 1u;                  // chunk ids from 1
-                                const unsigned old = atomicCAS(s_overflow + 2, 0u, mine);
-                                ch = old == 0u ? mine : old;
-                            }
-                        }
+                        if (lane == 0) ch = detect_claim_chunk(spill_flags, s_overflow + 2, (unsigned)blk, (unsigned)b);
                         ch = (unsigned)__builtin_amdgcn_readfirstlane((int)ch);
-                        if (ch > (unsigned)n_spill) { dense = true; n_mine = 0; break; }      // no chunk left: the band is redone by k_detect_redo
-                        unsigned *const chunk = spill + (size_t)(ch - 1u) * DET_SPILL_CHUNK;
+                        unsigned *const chunk = spill + (size_t)(ch - 1u) * (unsigned)chunk_entries;
                         const unsigned idx = base + rank_in_chunk;
-                        if (hit) {
-                            if (idx < (unsigned)pos_cap) s_pos[idx] = ent;
-                            else chunk[idx - (unsigned)pos_cap] = ent;
-                        }
+                        if (hit && idx < (unsigned)pos_cap) s_pos[idx] = ent;
+                        if (hit && idx >= (unsigned)pos_cap) chunk[idx - (unsigned)pos_cap] = ent;
                     }
                 }
             } else {
@@ -529,10 +544,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 #endif
     int e_cur = (rb_first << 8) + e_lane;                  // list entry of the lane's first pixel in the current step
     for (int rbase = rb_first; rbase < rb_end; rbase += step_rows) {
-        if (n_mine > flush_at) {
-            DET_RING_PASS(false);
-            if (CP && dense) break;                      // the wave has given up (its positives do not fit): the band is redone by k_detect_redo
-        }
+        if (n_mine > flush_at) DET_RING_PASS(false);
         const int ry = rbase + sub;
         const int y = y0 - 1 + ry;
         const unsigned *rowp = reinterpret_cast<const unsigned *>(lane_img + (rbase + 3) * S);
@@ -639,9 +651,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 #ifdef DET_TIMING
     DET_TACC(3, t_p1 + t_ring, t_p2); DET_TACC(4, 0ull, t_ring);
 #endif
-    if constexpr (CP) {
-        if (dense && lane == 0) s_overflow[0] = 1u;
-    }
     __syncthreads();
     DET_T(t_p3);
     DET_TACC(5, t_p2, t_p3);
@@ -651,18 +660,9 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     int n_all = 0;                                        // compact form: positives of the band (pool + spill chunk)
     const unsigned *spill_chunk = nullptr;
     if constexpr (CP) {
-        // ---- compact form: a band that found no room for its positives is listed for k_detect_redo; otherwise the score plane is built now, where the
-        // image tile and the survivor lists were (every wave is past them) ----
+        // ---- compact form: the score plane is built now, where the image tile and the survivor lists were (every wave is past them) ----
         n_all = (int)s_overflow[1];
-        if (n_all > pos_cap) spill_chunk = spill + (size_t)(s_overflow[2] - 1u) * DET_SPILL_CHUNK;
-        if (s_overflow[0] != 0u) {                        // (one LDS word: the same for every thread of the workgroup)
-            if (tid == 0) {
-                const unsigned slot = atomicAdd(redo, 1u);
-                redo[4 + 2 * slot] = (unsigned)b;
-                redo[5 + 2 * slot] = (unsigned)blk;
-            }
-            return;
-        }
+        if (n_all > pos_cap) spill_chunk = spill + (size_t)(s_overflow[2] - 1u) * (unsigned)chunk_entries;
         // The whole workgroup zeroes the plane with 16-byte stores, a barrier, then thread i scatters entries i, i + 256, ... (pool, then spill chunk).
         // (A form with one barrier less - every wave zeroes the rows it owned in phase 1 and scatters the entries of those rows - was slower: ~30 dword
         // stores per lane instead of 4 wide ones, and every wave reads the whole pool: 110.5 k against 112.5 k pairs/s.)
@@ -672,10 +672,17 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             uint4 *z = reinterpret_cast<uint4 *>(s_score);
             for (int i = tid; i < n16; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
             __syncthreads();
-            for (int i = tid; i < n_all; i += DET_THREADS) {
-                const unsigned e = i < pos_cap ? s_pos[i] : spill_chunk[i - pos_cap];
+            // (two loops, not one with a select between the pool and the chunk: a pointer that may be either makes every load a flat_load)
+            const int n_lds = min(n_all, pos_cap);
+            for (int i = tid; i < n_lds; i += DET_THREADS) {
+                const unsigned e = s_pos[i];
                 s_score[__umul24((e >> 8) & 255u, (unsigned)sstr) + (e & 255u)] = (unsigned short)(e >> 16);
             }
+            if (spill_chunk)
+                for (int i = tid; i < n_all - pos_cap; i += DET_THREADS) {
+                    const unsigned e = spill_chunk[i];
+                    s_score[__umul24((e >> 8) & 255u, (unsigned)sstr) + (e & 255u)] = (unsigned short)(e >> 16);
+                }
         }
         __syncthreads();
     }
@@ -714,10 +721,16 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         }
     };
     if constexpr (CP) {
-        for (int i = tid; i < n_all; i += DET_THREADS) {      // by entry index: every thread of the workgroup takes its share, whichever wave found the positive
-            const unsigned e = i < pos_cap ? s_pos[i] : spill_chunk[i - pos_cap];
+        const int n_lds = min(n_all, pos_cap);
+        for (int i = tid; i < n_lds; i += DET_THREADS) {      // by entry index: every thread of the workgroup takes its share, whichever wave found the positive
+            const unsigned e = s_pos[i];
             nms_one((int)((e >> 8) & 255u), (int)(e & 255u), (int)(e >> 16));
         }
+        if (spill_chunk)
+            for (int i = tid; i < n_all - pos_cap; i += DET_THREADS) {
+                const unsigned e = spill_chunk[i];
+                nms_one((int)((e >> 8) & 255u), (int)(e & 255u), (int)(e >> 16));
+            }
     } else if (!dense) {
         for (int i = lane; i < n_pos; i += 64) {
             const int e = my_list[i];
@@ -732,6 +745,10 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     }
     DET_T(t_p3e);
     __syncthreads();
+    if constexpr (CP) {
+        // every thread has read its spilled entries (the barrier waits for outstanding loads): the chunk goes back to the arena
+        if (tid == 0 && spill_chunk) __hip_atomic_store(spill_flags + (s_overflow[2] - 1u), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     DET_T(t_p4);
     DET_TACC(6, t_p3, t_p3e); DET_TACC(7, t_p3e, t_p4);
 #if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 4
@@ -847,34 +864,15 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 
 template <bool HAS_MASK, bool COMPASS, bool SWAR, bool CP>
 __global__ __launch_bounds__(DET_THREADS) void k_detect(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images, unsigned *redo, unsigned *spill, int n_spill)
+                                                const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, int n_images,
+                                                unsigned *spill, unsigned *spill_flags, int chunk_entries)
 {
     // every workgroup-independent kernel argument is pulled into SGPRs by the FIRST round of scalar loads (left alone, the
     // compiler loads each one right before its use, i.e. in 5 dependent rounds before the first image byte can be requested)
     asm volatile("" ::"s"(lut_bits), "s"(slab), "s"(tile_out), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.threshold));
     int b, blk;
     if (!xcd_map(g.detect_blocks, n_images, b, blk)) return;
-    detect_workgroup<HAS_MASK, COMPASS, SWAR, CP>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk, redo, spill, n_spill);
-}
-
-// Behind every compact launch: the bands that found neither room in their pool nor a spill chunk (a whole batch of noise images), through the
-// full-plane form (whose waves fall back to a dense scan of their rows, so it always finishes).  Normally redo[0] == 0 and the launch is 64
-// workgroups that read one word and leave.  The last workgroup to finish resets the list and the spill arena for the lane's next batch
-// (redo[1] counts the workgroups that are done).
-template <bool HAS_MASK, bool COMPASS, bool SWAR>
-__global__ __launch_bounds__(DET_THREADS) void k_detect_redo(Geometry g, ImageSrc src, const uint8_t *slab, const uint8_t *mask_slab,
-                                                     const uint32_t *__restrict__ lut_bits, unsigned long long *tile_out, unsigned *redo)
-{
-    const unsigned n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-        const int b = (int)__builtin_amdgcn_readfirstlane(redo[4 + 2 * i]), blk = (int)__builtin_amdgcn_readfirstlane(redo[5 + 2 * i]);
-        detect_workgroup<HAS_MASK, COMPASS, SWAR, false, true>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk);
-        __syncthreads();                                  // the next band re-uses the LDS
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0u; redo[1] = 0u; redo[2] = 0u; }      // every workgroup has read n and finished its bands: list and spill arena are free again
-    }
+    detect_workgroup<HAS_MASK, COMPASS, SWAR, CP>(g, src, slab, mask_slab, lut_bits, tile_out, b, blk, spill, spill_flags, chunk_entries);
 }
 
 // Single frames: k_blur does not depend on k_detect (both read the pyramid), and a frame is a chain of small launches whose latencies add up -
@@ -898,24 +896,13 @@ __global__ __launch_bounds__(DET_THREADS) void k_detect_blur(Geometry g, ImageSr
         else            { if (!g.lut_compass) LAUNCH(false, false, false); else if (g.det_swar_t4 > 0) LAUNCH(false, true, true); else LAUNCH(false, true, false); }     \
     } while (0)
 
-// redo: the lane's side-channel block (compact handles; detect_redo_words() per image slot, zero before the first launch); spill: the lane's arena
-// (detect_spill_bytes() per image slot) - the redo pass follows on the same stream
-size_t detect_redo_words(const Geometry &g) { return 4 + 2 * (size_t)g.detect_blocks; }
-size_t detect_spill_bytes() { return (size_t)DET_SPILL_PER_IMAGE * DET_SPILL_CHUNK * sizeof(unsigned); }
-size_t detect_spill_chunks_per_image() { return DET_SPILL_PER_IMAGE; }
+// spill / spill_flags: the handle's arena of spill chunks and their busy flags (compact handles; flags zero at creation, every workgroup returns its chunk)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
-                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s, unsigned *redo, size_t redo_lds_bytes, unsigned *spill)
+                   const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s, unsigned *spill, unsigned *spill_flags)
 {
     if (g.det_compact) {
-        const int n_spill = DET_SPILL_PER_IMAGE * n_images;
-#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, true>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, redo, spill, n_spill)
-        DETECT_DISPATCH(DETECT_LAUNCH);
-#undef DETECT_LAUNCH
-        static const bool no_redo = getenv("JSORB_EXPERIMENT_NO_REDO") != nullptr;      // timing experiment only (results are wrong as soon as a band needs the redo pass or the arena runs out)
-        if (no_redo) return;
-        const long total = (long)g.detect_blocks * n_images;
-        const unsigned grid = (unsigned)std::min<long>(total, 64);
-#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect_redo<M, C, S>), dim3(grid), dim3(DET_THREADS), redo_lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, redo)
+        const int chunk_entries = detect_spill_chunk_entries(g);
+#define DETECT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_detect<M, C, S, true>), xcd_grid(g.detect_blocks, n_images), dim3(DET_THREADS), lds_bytes, s, g, src, slab, mask_slab, lut_bits, tile_out, n_images, spill, spill_flags, chunk_entries)
         DETECT_DISPATCH(DETECT_LAUNCH);
 #undef DETECT_LAUNCH
     } else {

@@ -166,7 +166,7 @@ def plan_launch(im_height, im_width, scale_factor, n_levels, tile_h=30, tile_w=3
     rc = lib.jsorb_plan_launch(C.byref(prm), out.ctypes.data, out.size)
     if rc != 0:
         raise JsorbError("jsorb_plan_launch rc=%d" % rc)
-    keys = ("levels", "compact", "detect_lds", "redo_lds", "pyramid_lds", "detect_blocks", "spill_chunk_entries", "spill_chunks_per_image")
+    keys = ("levels", "compact", "detect_lds", "spill_chunks", "pyramid_lds", "detect_blocks", "spill_chunk_entries", "reserved")
     res = dict(zip(keys, (int(v) for v in out[:8])))
     lk = ("det_R", "k_tiles", "pool", "score_stride", "list_cap", "pyr_ns16", "pyr_ns_dispatched", "tile_rows")
     res["per_level"] = [dict(zip(lk, (int(v) for v in out[8 + 8 * i:16 + 8 * i]))) for i in range(res["levels"])]
