@@ -21,19 +21,23 @@
 
 namespace jsorb {
 
-// Work decomposition of a level (host): ROI = [20, H-20) x [20, W-20); strips of 8 columns x bands of blur_rb rows, item = band * strips + strip
+// Work decomposition of a level (host): ROI = [20, H-20) x [20, W-20); strips of 8 columns (the first one starts BLUR_X_LEAD = 4 columns in front of
+// the ROI, so that every lane's 8 output bytes are one aligned store) x bands of blur_rb rows, item = band * strips + strip
 // (adjacent lanes = adjacent strips: their 16-byte loads overlap by half and stay in the L1 lines of one image row), 256 items per workgroup.
 void fill_blur_layout(Geometry &g)
 {
     int bblk = 0;
     for (int i = 0; i < g.L; i++) {
         LevelDesc &lv = g.lv[i];
-        const int rw = lv.W - 2 * JSORB_BORDER, rh = lv.H - 2 * JSORB_BORDER;
+        const int rw = lv.W - 2 * JSORB_BORDER + BLUR_X_LEAD, rh = lv.H - 2 * JSORB_BORDER;      // (BLUR_X_LEAD border columns in front of the ROI belong to the first strip)
         lv.blur_blk0 = bblk;
         if (rw <= 0 || rh <= 0) { lv.blur_bx = 1; lv.blur_by = 0; lv.blur_rb = 1; lv.blur_recip = 0; continue; }
         const int ncs = (rw + BLUR_SW - 1) / BLUR_SW;
         // single-image handles: 8-row bands - twice the workgroups, half as long (k_blur of one EuRoC image 15-17 -> 8-11 us)
-        const int rb_max = getenv("JSORB_BLUR_ROWS") ? std::max(1, std::min(BLUR_RB_MAX, atoi(getenv("JSORB_BLUR_ROWS")))) : (g.latency ? 8 : BLUR_RB_MAX);
+        // batch handles: BLUR_RB_BATCH rows, and up to BLUR_RB_MAX on the BLUR_TALL_LEVELS largest levels (6 halo rows per band: 37 % more conversions and
+        // horizontal sums at 16 rows, 19 % at 32 - but a launch of 32-row bands everywhere ended in a long thin tail: 117.2 k against 120.0 k pairs/s)
+        const int rb_batch = i < BLUR_TALL_LEVELS ? BLUR_RB_MAX : BLUR_RB_BATCH;
+        const int rb_max = getenv("JSORB_BLUR_ROWS") ? std::max(1, std::min(BLUR_RB_MAX, atoi(getenv("JSORB_BLUR_ROWS")))) : (g.latency ? 8 : rb_batch);
         const int nrb = (rh + rb_max - 1) / rb_max;
         lv.blur_bx = ncs;                                   // strips per band
         lv.blur_by = nrb;                                   // bands

@@ -23,9 +23,23 @@ static __constant__ unsigned c_gauss_bits[7][4] = {
 
 #define BLUR_SW 8              // output pixels per lane and row
 #ifndef BLUR_RB_MAX
-#define BLUR_RB_MAX 16         // output rows per lane; per level the host evens the bands out (fill_blur_layout).  Measured at C2 (pairs/s): 32 rows
+#define BLUR_RB_MAX 16         // most output rows per lane; per level the host evens the bands out (fill_blur_layout).  Measured at C2 (pairs/s): 32 rows
                                // 117.2 k, 16 rows 120.0 k - six halo rows per band cost 37 % more conversions and horizontal sums, but a wave
                                // of 32-row bands lives for a third of the whole launch and the launch ends in a long, thin tail
+#endif
+#ifndef BLUR_RB_BATCH
+#define BLUR_RB_BATCH 16       // output rows per lane on the levels that are not "tall" (batch handles)
+#endif
+#ifndef BLUR_TALL_LEVELS
+#define BLUR_TALL_LEVELS 0     // the first n levels of a batch handle take bands of BLUR_RB_MAX rows
+#endif
+// Columns of the image border in front of the ROI that the FIRST strip of a row covers (0 or 4).  With 4, a lane's 8 output columns start at
+// 16 + 8 * strip: its store is one aligned 8-byte store (at 20 + 8 * strip it is two dword stores that straddle 8-byte units), and the four border
+// columns it covers are written as 0 - what the blurred plane holds outside the ROI anyway.
+// (measured at C2, A/B on one box: k_blur 0.192 -> 0.189 ms per step, 120.8 k -> 121.5 k pairs/s; 32-row bands on the 1 / 3 largest levels, tried in the same
+// run: k_blur 0.209 ms, 119.4 k / 118.4 k - the tail again)
+#ifndef BLUR_X_LEAD
+#define BLUR_X_LEAD 4
 #endif
 static_assert(BLUR_RB_MAX % 16 == 0 && BLUR_RB_MAX <= 32, "the per-lane row masks are read back as 16-byte units; list entries hold 5 bits of row");
 #define BLUR_THREADS 256
@@ -74,7 +88,7 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
 
     auto item_geometry = [&](int item, int &x0, int &ya) {
         const int band = ncs == 1 ? item : (int)__umulhi((unsigned)item, lv.blur_recip), strip = item - band * ncs;      // (2^32 / 1 does not fit the reciprocal)
-        x0 = JSORB_BORDER + BLUR_SW * strip;
+        x0 = JSORB_BORDER - BLUR_X_LEAD + BLUR_SW * strip;
         ya = JSORB_BORDER + band * RB;
     };
     const int item = wb * BLUR_THREADS + tid;
@@ -82,8 +96,8 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
     int x0, ya;
     item_geometry(live ? item : 0, x0, ya);
     const int n_out = live ? min(RB, H - JSORB_BORDER - ya) : 0;                  // output rows of this lane
-    const int n_valid = min(BLUR_SW, W - JSORB_BORDER - x0);                       // pixels of the strip inside the ROI (>= 1)
-    const unsigned px_mask = n_valid >= 8 ? 0xFFu : (1u << n_valid) - 1u;
+    const int n_valid = min(BLUR_SW, W - JSORB_BORDER - x0);                       // the strip's pixels up to the right end of the ROI (>= 1)
+    const unsigned px_mask = (n_valid >= 8 ? 0xFFu : (1u << n_valid) - 1u) & (BLUR_X_LEAD && x0 < JSORB_BORDER ? 0xFFu << (JSORB_BORDER - x0) : 0xFFu);      // pixels inside the ROI
 
     // weights in vector registers (a scalar operand halves the issue rate of the 2-clock instructions)
     float gh[4], gv[4];
@@ -167,7 +181,12 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
             }
             if (o < n_out) {
                 uint8_t *dst = out_base + (size_t)(ya + o) * out_pitch + x0;
-                if (n_valid >= BLUR_SW) { reinterpret_cast<unsigned *>(dst)[0] = ow[0]; reinterpret_cast<unsigned *>(dst)[1] = ow[1]; }
+                if (BLUR_X_LEAD) {
+                    // whole 8-byte units, zeros outside the ROI (the row's pitch has room for the last strip: pitch >= W rounded up to 64)
+                    const unsigned long long keep = ((px_mask & 1u) ? 0xFFull : 0) | ((px_mask & 2u) ? 0xFF00ull : 0) | ((px_mask & 4u) ? 0xFF0000ull : 0) | ((px_mask & 8u) ? 0xFF000000ull : 0) |
+                                                    ((px_mask & 16u) ? 0xFF00000000ull : 0) | ((px_mask & 32u) ? 0xFF0000000000ull : 0) | ((px_mask & 64u) ? 0xFF000000000000ull : 0) | ((px_mask & 128u) ? 0xFF00000000000000ull : 0);
+                    *reinterpret_cast<unsigned long long *>(dst) = (((unsigned long long)ow[1] << 32) | ow[0]) & keep;
+                } else if (n_valid >= BLUR_SW) { reinterpret_cast<unsigned *>(dst)[0] = ow[0]; reinterpret_cast<unsigned *>(dst)[1] = ow[1]; }
                 else {
 #pragma unroll
                     for (int k = 0; k < BLUR_SW; k++)
@@ -241,7 +260,8 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
     }
     // ---- dense exact path (bands of mostly flat windows): every pixel of the lane's strip through the reference's chain ----
     for (int o = 0; o < n_out; o++)
-        for (int k = 0; k < n_valid; k++) exact_pixel(x0 + k, ya + o);
+        for (int k = 0; k < n_valid; k++)
+            if ((px_mask >> k) & 1u) exact_pixel(x0 + k, ya + o);
 }
 
 } // namespace jsorb
