@@ -481,21 +481,34 @@ def main():
         # one launch of an extract-side kernel covers `per` images = per/2 stereo pairs; a stereo-side launch covers `per` pairs
         units = per if dom in ("k_stereo", "k_median") else per / 2.0
         achieved = ab * units / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, step_traffic = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.config, {}).get(dom)
+                per_kernel_traffic = tj.get(args.config if args.tile <= 0 else "", {})
+                traffic = per_kernel_traffic.get(dom)
                 traffic_source = tj.get("_source", "profiles/hbm_traffic.json") + " (builder-measured rocprofv3 PMC pass, NOT measured in this run)"
+                # HBM bytes of one step: every extract-side kernel runs twice (left and right images), the stereo-side ones once
+                if per_kernel_traffic and per == {"c2": 128}.get(args.config, 64):      # (the profile passes ran 128 images per launch at c2, 64 at c3 / c5: tools/profile_round.sh)
+                    step_traffic = sum((1 if k in ("k_stereo", "k_median") else 2) * v for k, v in per_kernel_traffic.items() if k.startswith("k_") and isinstance(v, (int, float)))
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "bound_note": "the contract's roofline is HBM bandwidth; what binds this integer / bitwise path is vector-instruction issue (bound_actual, valu_issue_frac)", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "bound_note": "the contract's roofline is HBM bandwidth; what binds this integer / bitwise path is vector-instruction issue (bound_actual, valu_issue_frac).  "
+                                               "frac is ALGORITHMIC bytes of the whole pipeline over the dominant kernel's launch time (the contract's convention): it moves with k_detect's duration only - "
+                                               "0.158 / 0.192 / 0.223 / 0.202 in rounds 1-4 (round 4 fell because k_detect's LDS request was raised on purpose, to leave room for a k_describe "
+                                               "workgroup per CU), ~0.26 with the compact k_detect of round 5.  kernel_own_hbm_frac is what that kernel itself moves over HBM", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_pair": ab, "pairs_per_launch": units,
                 "pipeline_achieved": round(ab * pairs_per_s / world / 1e9, 1),
                 "pipeline_frac": round(ab * pairs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step_ms.items()}}
+        if traffic:
+            roof["kernel_own_hbm_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)      # the dominant kernel's own PMC bytes / its duration / peak
+        if step_traffic:
+            roof["step_traffic_bytes"] = int(step_traffic)
+            roof["step_traffic_over_algorithmic"] = round(step_traffic / (ab * P), 3)
+            roof["step_traffic_frac"] = round(step_traffic / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)      # all HBM bytes of a step / step time / peak
         props = torch.cuda.get_device_properties(dev)
         vv = valu_view(args.config if args.tile <= 0 else "", pairs_per_s / world, props.multi_processor_count, props.clock_rate * 1e3 if getattr(props, "clock_rate", 0) else 2.4e9)
         if vv:
@@ -506,6 +519,8 @@ def main():
             roof["peak_measured_what"] = "1 GiB device-to-device copy, read + write bytes, best of 6 (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)"
             roof["frac_of_measured_peak"] = round(achieved / pm, 4)
             roof["pipeline_frac_of_measured_peak"] = round(ab * pairs_per_s / world / 1e9 / pm, 4)
+            if step_traffic:
+                roof["step_traffic_frac_of_measured_peak"] = round(step_traffic / (dt / args.steps) / 1e9 / pm, 4)
         cpu = None
         host_streamed = hs_multi
         frame_latency = None
@@ -558,6 +573,19 @@ def main():
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "placement": placements if world > 1 else [placement_info[0]],
         }
+        # the numbers a reader looks for first, once more at the END of the line (a log that keeps only the tail of the line still shows them)
+        def _v(d, *ks):
+            for k_ in ks:
+                d = d.get(k_) if isinstance(d, dict) else None
+            return d
+        out["summary"] = {"pairs_per_s": out["value"], "ms_per_step": out["ms_per_step"], "parity_vs_oracle": parity, "roofline_frac": roof.get("frac"),
+                          "dominant_kernel": dom, "dominant_kernel_ms": roof.get("avg_launch_ms"), "kernel_own_hbm_frac": roof.get("kernel_own_hbm_frac"),
+                          "step_traffic_frac_of_measured_peak": roof.get("step_traffic_frac_of_measured_peak"), "valu_issue_frac": roof.get("valu_issue_frac"),
+                          "cpu_baseline_pairs_per_s": _v(cpu, "value"), "host_streamed_pairs_per_s": _v(host_streamed, "value"),
+                          "frame_latency_us_median": _v(frame_latency, "total_us_median"), "frame_latency_us_p90": _v(frame_latency, "total_us_p90"),
+                          "frame_latency_us_median_persistent_threads": _v(frame_latency, "total_us_median_persistent_threads"),
+                          "c4_batch64_pairs_per_s": _v(c4, "value"),
+                          "other_configs_pairs_per_s": None if not other else {k_: _v(v_, "value") for k_, v_ in other.items()}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

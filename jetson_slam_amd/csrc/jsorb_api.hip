@@ -842,10 +842,15 @@ static void plan_detect(Geometry &g)
         uint8_t tr[256];
         g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !getenv("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
     }
-    // Batch handles run k_detect's compact form (score plane built late, on top of the dead image tile: 8 workgroups per CU) with k_detect_redo
-    // behind it; single-image handles the full-plane form (one image does not fill the chip, and the redo launch would sit on the frame's critical
-    // path).  JSORB_DETECT_FULLPLANE=1 gives a batch handle the full-plane form (the round-4 kernel: A/B measurements, tests).
-    g.det_compact = (!g.latency && !(getenv("JSORB_DETECT_FULLPLANE") && atoi(getenv("JSORB_DETECT_FULLPLANE")) != 0)) ? 1 : 0;
+    // Batch handles run k_detect's compact form (score plane built late, on top of the dead image tile; positives in an LDS pool that spills into a
+    // borrowed chunk of global memory: 7 workgroups per CU instead of 4) when the tiles are small enough for bands of several tile rows - measured
+    // against the full-plane form (kernel time / pairs per second of the 4-lane pipeline): C2 tile 30 -23 % / -1 %, C3 tile 25 -23 % / +-0, C5 tile 20
+    // -22 % / +2 %, but C2 with the "1000 features" tile 58 only -8 % / -6 % (one tile row per workgroup in either form, and the full-plane request
+    // leaves a k_describe workgroup its place on every CU).  Single-image handles keep the full-plane form (one image does not fill the chip).
+    // JSORB_DETECT_FULLPLANE=1 / 0 forces the full-plane / the compact form on a batch handle (A/B measurements, tests).
+    const char *force = getenv("JSORB_DETECT_FULLPLANE");
+    const bool want_compact = force ? atoi(force) == 0 : g.lv[0].th <= 40;
+    g.det_compact = (!g.latency && want_compact) ? 1 : 0;
     fill_detect_layout(g);
 }
 

@@ -38,16 +38,19 @@ def test_pyramid_lds_request_covers_the_instantiated_resampler(orb):
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_compact_detect_layout(orb, name):
-    """Batch handles run the compact k_detect: at most 18 LDS granules per workgroup (7 workgroups per CU) unless a single tile row needs more, a pool of
-    positives of >= 10 % of the band's region pixels, bands that never split a level's tile rows unevenly beyond the last one, and a spill chunk that
-    holds the largest band region (every pixel a positive) - so that no input can overflow it.  Single-image handles keep the full-plane form."""
+def test_compact_detect_layout(orb, name, monkeypatch):
+    """The compact k_detect (batch handles with tiles of at most 40 rows; forced here for every configuration): at most 18 LDS granules per workgroup
+    (7 workgroups per CU) unless a single tile row needs more, a pool of positives of >= 10 % of the band's region pixels, bands of whole tile rows,
+    and a spill chunk that holds the largest band region (every pixel a positive) - so that no input can overflow it.  Single-image handles keep the
+    full-plane form."""
     h, w, L, tile = CONFIGS[name]
+    monkeypatch.delenv("JSORB_DETECT_FULLPLANE", raising=False)
     single = orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=1)
     assert single["compact"] == 0 and single["spill_chunks"] == 0 and all(lv["det_R"] == 1 for lv in single["per_level"])      # latency layout: one tile row per workgroup
+    assert orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=64)["compact"] == (1 if tile <= 40 else 0)      # the default choice (jsorb_api.hip: plan_detect)
+    monkeypatch.setenv("JSORB_DETECT_FULLPLANE", "0")
     p = orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=64)
     assert p["compact"] == 1
-    one_row = orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=64)       # (the budget may only be exceeded where even ONE tile row does not fit)
     if all(lv["det_R"] > 1 or tile <= 30 for lv in p["per_level"]):
         assert p["detect_lds"] <= 18 * GRANULE, p["detect_lds"]
     assert p["detect_lds"] <= 64 * 1024
@@ -68,11 +71,10 @@ def test_compact_detect_layout(orb, name):
         assert 1 <= lv["det_R"] <= 4 and lv["det_R"] * th + 2 <= 255 and lv["det_R"] * lv["k_tiles"] <= 128
         blocks += -(-lv["tile_rows"] // lv["det_R"]) * (-(-ntw // lv["k_tiles"]))
     assert blocks == p["detect_blocks"]
-    del one_row
 
 
 def test_fullplane_knob_and_budget_knob_are_honoured():
-    """JSORB_DETECT_FULLPLANE=1 gives a batch handle the full-plane form; JSORB_DETECT_BUDGET raises the LDS budget the bands are chosen for."""
+    """JSORB_DETECT_FULLPLANE=1 / 0 forces the full-plane / compact form on a batch handle; JSORB_DETECT_BUDGET raises the LDS budget the bands are chosen for."""
     code = ("import sys; sys.path.insert(0, %r)\nfrom jetson_slam_amd import orb\np = orb.plan_launch(480, 752, 1.2, 8, 30, 30, max_batch=64)\n"
             "print(p['compact'], p['detect_lds'], p['detect_blocks'])") % ROOT
     def run(env):

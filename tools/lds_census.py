@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from jetson_slam_amd import build as b      # noqa: E402
 
 GRAN, CU_LDS, SIMD_VGPR, MAX_WAVES_SIMD = 1280, 160 * 1024, 512, 8
-KERNELS = {"k_pyramid.hip": "9k_pyramidILb0ELb0EE", "k_detect.hip": "8k_detectILb0ELb1ELb1EE", "k_compact.hip": "14k_compact_flatILi4EE", "k_blur.hip": "6k_blurE",
+KERNELS = {"k_pyramid.hip": "9k_pyramidILb0ELb0EE", "k_detect.hip": "8k_detectILb0ELb1ELb1ELb1EE", "k_compact.hip": "14k_compact_flatILi4EE", "k_blur.hip": "6k_blurE",
            "k_describe.hip": "10k_describeE", "k_stereo.hip": "8k_stereoE"}
 MEDIAN = ("k_stereo.hip", "8k_medianILi32EE")
 
@@ -38,7 +38,7 @@ def metadata(path, flags):
 
 
 def main():
-    dyn = {"k_detect": int(sys.argv[1]) if len(sys.argv) > 1 else 33280, "k_pyramid": int(sys.argv[2]) if len(sys.argv) > 2 else 3840}
+    dyn = {"k_detect": int(sys.argv[1]) if len(sys.argv) > 1 else 23040, "k_pyramid": int(sys.argv[2]) if len(sys.argv) > 2 else 3840}
     rows = {}
     for f, key in list(KERNELS.items()) + [MEDIAN]:
         md = metadata(os.path.join(b.CSRC, f), b.FILE_FLAGS.get(f, []))

@@ -32,6 +32,10 @@ KERNELS = {"k_pyramid.hip": ["k_pyramid"], "k_detect.hip": ["k_detect"], "k_blur
            "k_stereo.hip": ["k_stereo", "k_median"], "k_compact.hip": ["k_compact_flat"]}
 
 
+# the instantiation bench.py's default configuration launches (no mask, compass LUT, 6-bit early rejects, compact form)
+PREFERRED = {"k_detect": "8k_detectILb0ELb1ELb1ELb1E"}
+
+
 def issue_clocks(line):
     m = re.match(r"\s+(v_\w+)\s*(.*)", line)
     if not m:
@@ -75,7 +79,11 @@ def kernel_mix(asm_text, names):
             n_static += 1
             n2 += c == 2.0
         key = name
-        if key in out and out[key]["static_instructions"] >= n_static:      # several instantiations: keep the largest (the common one is picked by bench.py by name only)
+        preferred = PREFERRED.get(name)
+        if preferred:                                     # the instantiation the benchmark runs
+            if preferred not in sym:
+                continue
+        elif key in out and out[key]["static_instructions"] >= n_static:      # several instantiations: keep the largest
             continue
         out[key] = {"clk_per_valu_instr": round(tot_c / max(tot_w, 1e-9), 3), "static_instructions": n_static, "static_full_rate_share": round(n2 / max(n_static, 1), 3)}
     return out
