@@ -39,6 +39,11 @@ def test_bench_launches_two_ranks_itself_and_gathers_counts():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["pairs_per_step_total"] == 12
     assert d["parity_vs_oracle"] is True and d["gathered_counts_ok"] is True and d["parity_pairs_checked"] == 12
+    # what makes a first real multi-GPU run diagnosable: every rank's own median block time next to the max the value is made of, and the time of the all_gather itself
+    diag = d["multi_gpu_diag"]
+    assert len(diag["per_rank"]) == 2 and all(r_["median_block_ms"] > 0 and r_["ms_per_step"] > 0 and r_["all_gather_ms_mean"] >= 0 and r_["all_gather_ms_max"] >= r_["all_gather_ms_mean"]
+                                              for r_ in diag["per_rank"])
+    assert max(r_["ms_per_step"] for r_ in diag["per_rank"]) <= d["ms_per_step"] * 1.5 and d["summary"]["pairs_per_s"] == d["value"]
     # strong scaling shape (BASELINE C4 style): the total is split over the ranks
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--pairs-total", "8"],
                        env=_clean_env(JSORB_BENCH_SINGLE_DEVICE="1", JSORB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600, cwd=ROOT)
