@@ -31,8 +31,12 @@ static __constant__ unsigned c_gauss_bits[7][4] = {
 #define BLUR_RB_BATCH 16       // output rows per lane on the levels that are not "tall" (batch handles)
 #endif
 #ifndef BLUR_TALL_LEVELS
-#define BLUR_TALL_LEVELS 0     // the first n levels of a batch handle take bands of BLUR_RB_MAX rows
+#define BLUR_TALL_LEVELS 0     // the first n levels of a batch handle take bands of BLUR_RB_TALL rows
 #endif
+#ifndef BLUR_RB_TALL
+#define BLUR_RB_TALL BLUR_RB_MAX
+#endif
+static_assert(BLUR_RB_TALL <= BLUR_RB_MAX && BLUR_RB_BATCH <= BLUR_RB_MAX, "band heights are bounded by the per-lane mask bytes");
 // Columns of the image border in front of the ROI that the FIRST strip of a row covers (0 or 4).  With 4, a lane's 8 output columns start at
 // 16 + 8 * strip: its store is one aligned 8-byte store (at 20 + 8 * strip it is two dword stores that straddle 8-byte units), and the four border
 // columns it covers are written as 0 - what the blurred plane holds outside the ROI anyway.

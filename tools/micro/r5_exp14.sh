@@ -1,0 +1,13 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/../..}
+V=$PWD/jetson_slam_amd/csrc/_build/variants
+B="python bench.py --no-cpu-baseline --no-extras --min-time 1.5"
+fmt='import json,sys; d=json.loads(sys.stdin.readline()); k=d["roofline"]["kernel_ms_per_step"]; print("%-28s %8.1f pairs/s  %.4f ms/step  parity=%s  " % (sys.argv[1], d["value"], d["ms_per_step"], d["parity_vs_oracle"]) + " ".join("%s=%.4f" % (a[2:], b) for a, b in k.items() if b))'
+run() { name=$1; shift; env "$@" $B $EXTRA 2>gpurun_out/r5_exp14_err.txt | tail -1 | python -c "$fmt" "$name" || tail -5 gpurun_out/r5_exp14_err.txt; }
+for i in 1 2; do
+run current_16            X=1
+run blur32_mask_only      JSORB_LIBRARY=$V/blur32_mask_only/libjsorb.so
+run blur20_all            JSORB_LIBRARY=$V/blur20_all/libjsorb.so
+run blur24_all            JSORB_LIBRARY=$V/blur24_all/libjsorb.so
+run blur24_l4             JSORB_LIBRARY=$V/blur24_l4/libjsorb.so
+done
