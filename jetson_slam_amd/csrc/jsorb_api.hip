@@ -950,6 +950,9 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
     if (g.det_compact) {
+        int cus = 0;
+        HIPCHK(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        if (!detect_arena_covers(cus)) { e->err = "k_detect's spill arena is laid out for 8 XCDs of at most 32 CUs: set JSORB_DETECT_FULLPLANE=1 on this device"; return JSORB_ERR_UNSUPPORTED; }
         HIPCHK(e, hipMalloc(&e->det_spill, detect_arena_bytes(g)));
         HIPCHK(e, hipMalloc(&e->det_spill_flags, detect_arena_flag_words() * sizeof(unsigned)));
         HIPCHK(e, hipMemset(e->det_spill_flags, 0, detect_arena_flag_words() * sizeof(unsigned)));

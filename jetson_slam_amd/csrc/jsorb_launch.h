@@ -35,6 +35,7 @@ void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, 
 int detect_spill_chunk_entries(const Geometry &g);      // u32 entries of one spill chunk (the handle's largest band region)
 size_t detect_arena_bytes(const Geometry &g);           // the whole arena: 8 XCDs x slots x chunk
 size_t detect_arena_flag_words();                       // one busy flag per chunk
+bool detect_arena_covers(int compute_units);           // the arena has a chunk for every workgroup of the compact k_detect that can be resident on a device of this size (8 XCDs of <= 32 CUs)
 int detect_pos_cap(const Geometry &g, int level);   // entries of a k_detect workgroup's pool of positives on that level (compact form)
 void launch_nms_ms(const Geometry &g, unsigned long long *tile_out, int *ms_grid, int *ms_scratch, int mode_gpu, int n_images, hipStream_t s);
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,

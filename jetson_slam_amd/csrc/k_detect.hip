@@ -218,6 +218,8 @@ int detect_spill_chunk_entries(const Geometry &g)
 }
 size_t detect_arena_bytes(const Geometry &g) { return (size_t)DET_ARENA_XCDS * DET_ARENA_SLOTS * detect_spill_chunk_entries(g) * sizeof(unsigned); }
 size_t detect_arena_flag_words() { return (size_t)DET_ARENA_XCDS * DET_ARENA_SLOTS; }
+// workgroups of the compact k_detect that may be resident at once on this many CUs (4 waves each, 32 wave slots per CU) must not exceed the arena's chunks
+bool detect_arena_covers(int compute_units) { return (long)compute_units * 8 <= (long)DET_ARENA_XCDS * DET_ARENA_SLOTS && compute_units <= 32 * DET_ARENA_XCDS; }
 int detect_pos_cap(const Geometry &g, int level) { return g.lv[level].det_pos_cap; }
 
 // Early rejects on 6-bit pixels (k_detect phase 1, SWAR form): with q(x) = x >> 2 and t4 = (th + 1) >> 2,
