@@ -295,7 +295,7 @@ __device__ __attribute__((noinline)) unsigned detect_claim_chunk(unsigned *spill
     const unsigned mine = xcc * DET_ARENA_SLOTS + slot + 1u;
     const unsigned old = atomicCAS(s_chunk, 0u, mine);
     if (old == 0u) return mine;
-    __hip_atomic_store(fl + slot, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fl + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nothing was written to the chunk)
     return old;
 }
 
@@ -749,7 +749,9 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     __syncthreads();
     if constexpr (CP) {
         // every thread has read its spilled entries (the barrier waits for outstanding loads): the chunk goes back to the arena
-        if (tid == 0 && spill_chunk) __hip_atomic_store(spill_flags + (s_overflow[2] - 1u), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (a relaxed store: the chunk's next user runs on the same XCD and reaches the chunk through the same L2 as this workgroup's stores - an agent-scope
+        // release would write the whole L2 back)
+        if (tid == 0 && spill_chunk) __hip_atomic_store(spill_flags + (s_overflow[2] - 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     DET_T(t_p4);
     DET_TACC(6, t_p3, t_p3e); DET_TACC(7, t_p3e, t_p4);
