@@ -308,7 +308,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
 #ifdef DET_TIMING
-    unsigned long long det_t[9] = {};
+    unsigned long long det_t[10] = {};
 #endif
     DET_T(t_start);
     // workgroup descriptor (level, tile row, tile group) from the host-built table behind the LUT: one scalar load instead of a
@@ -688,6 +688,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         }
         __syncthreads();
     }
+    DET_T(t_plane);
+    DET_TACC(9, t_p3, t_plane);                           // compact form: zero + barrier + scatter + barrier
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + arg-max key, positives of the wave's own list ----
     // (list entries always have a positive score; the `s > 0` test only matters for the dense fallback)
@@ -754,7 +756,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         if (tid == 0 && spill_chunk) __hip_atomic_store(spill_flags + (s_overflow[2] - 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     DET_T(t_p4);
-    DET_TACC(6, t_p3, t_p3e); DET_TACC(7, t_p3e, t_p4);
+    DET_TACC(6, t_plane, t_p3e); DET_TACC(7, t_p3e, t_p4);
 #if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 4
     if (tile_out) return;
 #endif
@@ -783,7 +785,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 #ifdef DET_TIMING
         if (lane == 0) {
             unsigned long long *slot = g_det_timing[(blockIdx.x + 8 * blockIdx.y + 977 * blockIdx.z + 131 * wave) & (DET_TSLOTS - 1)];
-            for (int k = 0; k < 9; k++) atomicAdd(slot + k, det_t[k]);
+            for (int k = 0; k < 10; k++) atomicAdd(slot + k, det_t[k]);
         }
 #endif
         return;

@@ -32,8 +32,8 @@ for rep in range(3):
     L.jsorb_debug_detect_timing(out)
 t = [int(x) for x in out]
 names = ["waves", "prologue + staging", "barrier after staging", "phase 1 early rejects + appends", "phase 2 ring passes", "barrier after phase 2",
-         "phase 3 NMS + arg-max", "barrier after phase 3", "phase 4 decode"]
-tot = sum(t[1:9])
+         "phase 3 NMS + arg-max", "barrier after phase 3", "phase 4 decode", "compact form: plane build (zero, barrier, scatter, barrier)"]
+tot = sum(t[1:10])
 print("k_detect %s, %d images: %d waves, %.0f clocks per wave" % (name, n, t[0], tot / max(t[0], 1)))
-for k in range(1, 9):
+for k in (1, 2, 3, 4, 5, 9, 6, 7, 8):
     print("  %-36s %6.1f %%   %8.0f clk per wave" % (names[k], 100.0 * t[k] / tot, t[k] / max(t[0], 1)))
