@@ -759,7 +759,7 @@ void spec_after_extract(jsorb_extractor *e, int n)
     if (ok) {
         const StereoArgs sa = make_stereo_args(S->mb, S->mbf, S->th_high, S->th_low);
         launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts, r->desc, r->row_tab,
-                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st);
+                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st, nullptr, DeliverStereo{l->h_sp_u, l->h_sp_d, nullptr});
         launch_median(l->g, l->counts, l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, l->sp_stats, 1, st, DeliverStereo{l->h_sp_u, l->h_sp_d, l->h_sp_stats});
         ok = hipGetLastError() == hipSuccess && hipEventRecord(S->ev_done, st) == hipSuccess;
         // whatever went out on the stream reads both handles' buffers: their next extracts are ordered after it in any case
@@ -1563,7 +1563,8 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
                                               l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_stride,
                                               l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st,
-                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr));
+                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr,
+                                              direct ? DeliverStereo{l->h_u, l->h_d, nullptr} : DeliverStereo{nullptr, nullptr, nullptr}));
         TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
                                               l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, l->h_stats + f * 8}));
         HIPCHK(l, hipGetLastError());
