@@ -1639,6 +1639,11 @@ int jsorb_set_stereo_diagnostics(jsorb_extractor *l, int on)
         const size_t n = (size_t)l->B * l->g.T * JSORB_STEREO_DIAG_INTS * sizeof(int);
         HIPCHK(l, hipMalloc(&l->st_diag, n));
         HIPCHK(l, hipMemset(l->st_diag, 0xFF, n));
+        // hipMemset on device memory returns before the fill has run, and the fill is ordered with the NULL stream only - the handles' streams are non-blocking.
+        // Without this wait the fill could land on top of what the next k_stereo had already written: the arg-min / window-list diagnostics of a few hundred
+        // keypoints read back as -1 while every product output was right (caught by tools/micro/chain_stress.py in round 5: 1 iteration in ~6 000; in all
+        // likelihood also the "unexplained failure of the full GPU suite" of round 4, the round that introduced this hook and the test that reads it)
+        HIPCHK(l, hipDeviceSynchronize());
     } else if (!on && l->st_diag) {
         HIPCHK(l, hipDeviceSynchronize());
         HIPCHK(l, hipFree(l->st_diag));
