@@ -72,6 +72,18 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    """model string of the host CPU (the CPU baseline states core count AND model)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(cfg, lefts, rights, budget_s=12.0):
     """The oracle (kind 'port': the reference has no CPU path), OpenMP over independent pairs on all host
     cores, built -O3 -march=native on this box, same workload, bounded to ~budget_s of wall time."""
@@ -86,8 +98,8 @@ def cpu_baseline(cfg, lefts, rights, budget_s=12.0):
     kw = dict(height=H, width=W, n_levels=L, tile_h=tile, tile_w=tile, th_fast_max=th)
     n1, t1 = po.bench_pairs(lefts, rights, bf / fx, bf, 2.0, 1, native=native, **kw)
     n, t = po.bench_pairs(lefts, rights, bf / fx, bf, budget_s, cores, native=native, **kw)
-    return {"value": round(n / t, 2), "unit": "stereo pairs/s", "cores": cores, "kind": "port",
-            "single_thread_value": round(n1 / t1, 2),
+    return {"value": round(n / t, 2), "unit": "stereo pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "host_logical_cpus": os.cpu_count(), "single_thread_value": round(n1 / t1, 2),
             "sample": "%d pairs (cycling %d unique synthetic pairs of the same workload) in %.1f s on %d OpenMP threads; "
                       "oracle built -O3 -march=native=%s" % (n, len(lefts), t, cores, native)}
 
@@ -525,6 +537,7 @@ def main():
         host_streamed = hs_multi
         frame_latency = None
         other = None
+        other_inputs = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, left_u[:16], right_u[:16])
         if world == 1 and not args.no_extras:
@@ -542,7 +555,16 @@ def main():
                     pass
             for h in handles:
                 h.close()
-            frame_latency = measure_frame_latency(cfg, left_u[:4], right_u[:4])
+            try:                                        # the C++ driver's threads inherit the binding: same NUMA node as the GPU (round-5 review)
+                if placement_info[0] and placement_info[0].get("bound") and placement_info[0].get("cpus"):
+                    from jetson_slam_amd import placement
+                    os.sched_setaffinity(0, set(placement.parse_cpulist(placement_info[0]["cpus"])))
+                frame_latency = measure_frame_latency(cfg, left_u[:4], right_u[:4])
+            finally:
+                try:
+                    os.sched_setaffinity(0, saved_affinity)
+                except OSError:
+                    pass
             if args.config == "c2" and args.tile <= 0 and not strong:
                 # BASELINE C3 / C5 and the "nominal feature count" tiles of SURVEY 8(d), ~1 s each, every unique pair checked
                 other = {}
@@ -552,6 +574,16 @@ def main():
                         other[key] = measure_other_config(orb, torch, dev, nm, tl, pp, nu)
                     except Exception as e:      # never let a side measurement break the contract line
                         other[key] = {"error": str(e)[:200]}
+                # other image statistics at the headline geometry (round-5 review: every list / pool size was tuned on ONE generator): C2, batch 128,
+                # 16 unique pairs of each family checked against the oracle
+                from jetson_slam_amd.synth import INPUT_FAMILIES
+                other_inputs = {}
+                for fam in INPUT_FAMILIES:
+                    try:
+                        other_inputs[fam] = measure_other_config(orb, torch, dev, "c2", 0, 128, 16, family=fam)
+                        other_inputs[fam]["frac_of_headline"] = round(other_inputs[fam]["value"] / pairs_per_s, 3)
+                    except Exception as e:
+                        other_inputs[fam] = {"error": str(e)[:200]}
         n0 = int(o_counts[0][0])
         out = {
             "metric": "stereo pairs/s (FAST+ORB extract L+R + stereo match)", "value": round(pairs_per_s, 1), "unit": "stereo pairs/s",
@@ -569,7 +601,7 @@ def main():
                        "block_ms_min": round(min(blocks) * 1e3, 3), "block_ms_max": round(max(blocks) * 1e3, 3)},
             "parity_vs_oracle": parity, "parity_pairs_checked": n_unique * n_sets * world, "gathered_counts_ok": counts_ok if world > 1 else None,
             "roofline": roof, "cpu_baseline": cpu, "host_streamed": host_streamed, "frame_latency_us": frame_latency, "c4_batch64": c4, "multi_gpu_diag": multi_diag,
-            "other_configs": other, "rccl_init_s": None if rccl_init_s is None else round(rccl_init_s, 3),
+            "other_configs": other, "other_inputs": other_inputs, "rccl_init_s": None if rccl_init_s is None else round(rccl_init_s, 3),
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "placement": placements if world > 1 else [placement_info[0]],
         }
@@ -585,7 +617,8 @@ def main():
                           "frame_latency_us_median": _v(frame_latency, "total_us_median"), "frame_latency_us_p90": _v(frame_latency, "total_us_p90"),
                           "frame_latency_us_median_persistent_threads": _v(frame_latency, "total_us_median_persistent_threads"),
                           "c4_batch64_pairs_per_s": _v(c4, "value"),
-                          "other_configs_pairs_per_s": None if not other else {k_: _v(v_, "value") for k_, v_ in other.items()}}
+                          "other_configs_pairs_per_s": None if not other else {k_: _v(v_, "value") for k_, v_ in other.items()},
+                          "other_inputs_pairs_per_s": None if not other_inputs else {k_: _v(v_, "value") for k_, v_ in other_inputs.items()}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -676,18 +709,19 @@ def timed_steps(handles, step, fence, n_steps):
     return out
 
 
-def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seconds=0.8, cache={}):
+def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seconds=0.8, cache={}, family=None):
     """The other BASELINE configurations in the driver-run line: device-resident batches of P pairs through ONE handle pair, every unique pair
-    checked against the oracle, per-kernel hipEvent pass for the dominant kernel's roofline fraction."""
-    from jetson_slam_amd.synth import synth_stereo_pair
+    checked against the oracle, per-kernel hipEvent pass for the dominant kernel's roofline fraction.
+    family: another image statistic than synth_stereo_pair (jetson_slam_amd.synth.INPUT_FAMILIES) - the line's `other_inputs`."""
+    from jetson_slam_amd.synth import synth_stereo_pair, synth_family_pair
     from oracle import pyoracle as po
     H, W, L, tile, th, fx, bf = CONFIGS[name]
     if tile_override:
         tile = tile_override
-    if name not in cache:
-        prs = [synth_stereo_pair(1 + i, H, W) for i in range(n_unique)]
-        cache[name] = (np.stack([q[0] for q in prs]), np.stack([q[1] for q in prs]))
-    left_u, right_u = cache[name]
+    if (name, family) not in cache:
+        prs = [synth_family_pair(family, 1 + i, H, W) if family else synth_stereo_pair(1 + i, H, W) for i in range(n_unique)]
+        cache[(name, family)] = (np.stack([q[0] for q in prs]), np.stack([q[1] for q in prs]))
+    left_u, right_u = cache[(name, family)]
     idx = np.arange(P) % left_u.shape[0]
     left_d, right_d = torch.from_numpy(left_u[idx]).to(dev), torch.from_numpy(right_u[idx]).to(dev)
     mk = lambda: orb.ORBExtractor(H, W, 1.2, L, 9, 14, 7, th, None, tile, tile, device_id=dev.index or 0, max_batch=P)
@@ -742,7 +776,10 @@ def measure_other_config(orb, torch, dev, name, tile_override, P, n_unique, seco
            "algo_bytes_per_pair": ab, "pipeline_frac": round(ab * pps / 1e9 / HBM_PEAK_GBS, 4),
            "kernel": dom, "frac": round(ab * units / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4),
            "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()}}
-    if not tile_override:
+    if family:
+        out["workload"] += "; input family '%s' (jetson_slam_amd.synth.synth_family_pair)" % family
+        out["keypoints_mean"] = round(float(np.mean(o_counts[:, 0])), 1)
+    if not tile_override and not family:
         props = torch.cuda.get_device_properties(dev)
         vv = valu_view(name, pps, props.multi_processor_count, props.clock_rate * 1e3 if getattr(props, "clock_rate", 0) else 2.4e9)
         if vv and "valu_issue_frac" in vv:
@@ -798,7 +835,7 @@ def measure_host_streamed(orb, torch, cfg, left_u, right_u, dev, P=256, seconds=
             "sample": "%d steps of %d pairs from pinned host memory (jsorb_extract_batch_host_async), %.2f s" % (n, P, dt)}
 
 
-def measure_frame_latency(cfg, left, right, frames=300):
+def measure_frame_latency(cfg, left, right, frames=300, launches=3):
     """north-star regime: ONE stereo pair per call through the reference-shaped synchronous C++ API (two std::threads for L/R,
     SyncedMem::to_cpu x 4, ComputeStereoMatches) - tools/micro/frame_latency.cpp, built by __graft_entry__.build().  left / right: a few
     different pairs [n, H, W] that the driver rotates through (consecutive frames differ, as they do in a SLAM session)."""
@@ -813,9 +850,21 @@ def measure_frame_latency(cfg, left, right, frames=300):
         left.tofile(lp); right.tofile(rp)
         env = dict(os.environ, JSORB_JSON="1", JSORB_ROTATE_PAIRS=str(left.shape[0]))
         try:
-            out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=env,
-                                 capture_output=True, text=True, timeout=120)
-            res = json.loads(out.stdout.strip().splitlines()[-1])
+            # THREE process launches of the default shape (round-5 review: one launch per figure, 16 %% apart between boxes and runs): the figures of the
+            # line are the medians over the launches, every launch's own median / p10 / p90 stays in `launches`
+            runs = []
+            for _ in range(launches):
+                out = subprocess.run([exe, str(H), str(W), str(L), str(tile), str(th), str(fx), str(bf), lp, rp, str(frames)], env=env,
+                                     capture_output=True, text=True, timeout=120)
+                runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+            res = dict(sorted(runs, key=lambda r_: r_["total_us_median"])[len(runs) // 2])      # the launch with the median median
+            for key in ("total_us_median", "total_us_p10", "total_us_p90", "thread_spawn_us"):
+                res[key] = round(median([r_[key] for r_ in runs]), 1)
+            res["launches"] = [{k_: r_[k_] for k_ in ("total_us_median", "total_us_p10", "total_us_p90", "thread_spawn_us")} for r_ in runs]
+            res["total_us_median_spread"] = [min(r_["total_us_median"] for r_ in runs), max(r_["total_us_median"] for r_ in runs)]
+            res["threads"] = ("the driver process is bound to the cores of the GPU's NUMA node (jetson_slam_amd/placement.py; `placement` in this line) - its two "
+                              "extractor threads are spawned per frame as in Frame.cpp:107-110; thread_spawn_us = two NO-OP std::threads spawned and joined, "
+                              "timed in the same loop")
             res["what"] = ("C++ driver shaped like Frame::Frame: extract L||R in two std::threads + 4 x SyncedMem::to_cpu + ComputeStereoMatches, host images in "
                            "pageable memory; the match of frame k is enqueued by the library behind the extracts of frame k (jsorb_set_speculative_stereo) and "
                            "adopted by ComputeStereoMatches - total_us_plain is the same driver with JSORB_SPECULATE=0")

@@ -42,7 +42,7 @@ struct TimedLaunch { int id; hipEvent_t a, b; };
 // JSORB_NO_ENV=1 forbids it: an integrator who does not want a library to touch the process environment sets the variable itself (or not).
 __attribute__((constructor)) void jsorb_runtime_defaults()
 {
-    const char *no = getenv("JSORB_NO_ENV");
+    const char *no = product_env("JSORB_NO_ENV");
     if (!(no && atoi(no) != 0)) setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
@@ -90,8 +90,6 @@ struct jsorb_extractor {
     hipEvent_t ev_fork = nullptr;
     int max_lanes = 4;
     int spin_wait = 1;                 // poll instead of block when waiting for a single frame (JSORB_SPIN_WAIT=0 disables)
-    int stagger = 0;                   // software pipeline across lanes (JSORB_LANE_STAGGER=1; measured slower: 77.8 k vs 80 k pairs/s)
-    hipEvent_t ev_stage[JSORB_MAX_LANES][6] = {};
     double lane_min_px = 7.0e6;
     int K = 1;                 // lanes used by the last batch
     int lane_first[JSORB_MAX_LANES + 1] = {};
@@ -214,7 +212,7 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
     if (!(p.scale_factor > 1.0f) && p.n_levels > 1) { err = "scale_factor must be > 1"; return JSORB_ERR_INVALID; }
     memset(&g, 0, sizeof(g));
     g.L = p.n_levels;
-    g.latency = p.max_batch <= 1 && !(getenv("JSORB_THROUGHPUT_LAYOUT") && atoi(getenv("JSORB_THROUGHPUT_LAYOUT")) != 0);
+    g.latency = p.max_batch <= 1 && !(product_env("JSORB_THROUGHPUT_LAYOUT") && atoi(product_env("JSORB_THROUGHPUT_LAYOUT")) != 0);
     g.threshold = p.th_fast_max;   // th_FAST_MIN is overwritten in the reference (orb_gpu.cpp:42-47)
     float scale[JSORB_MAX_LEVELS], inv[JSORB_MAX_LEVELS];
     scale[0] = 1.0f; inv[0] = 1.0f;
@@ -274,13 +272,13 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
     // the disparity window reaches 15), 0.160 -> 0.145 ms KITTI-shaped, 0.65 -> 0.52 ms KAIST-shaped (64 tiles per row, 23 in the window).
     // JSORB_STEREO_COLPRUNE=0 restores the whole-row scan.
     g.stereo_colprune = 1;
-    if (const char *cp = getenv("JSORB_STEREO_COLPRUNE")) g.stereo_colprune = atoi(cp) != 0;
+    if (const char *cp = experiment_env("JSORB_STEREO_COLPRUNE")) g.stereo_colprune = atoi(cp) != 0;
     // Scan-line buckets (k_compact sorts the keypoints by level and level-0 row, k_stereo scans the few buckets around the left keypoint's
     // row instead of whole tile rows): 370 -> 35 right keypoints looked at per left keypoint at the EuRoC shape.  Needs the flat k_compact
     // (T <= 65536), L * H0 counters in its LDS, and level-0 coordinates that fit 16 bits.  JSORB_STEREO_EPI=0 keeps the tile-based scan.
     g.epi_rows = 0; g.epi_off = 0;
     {
-        const bool want = !(getenv("JSORB_STEREO_EPI") && atoi(getenv("JSORB_STEREO_EPI")) == 0);
+        const bool want = !env_is(experiment_env("JSORB_STEREO_EPI"), 0);
         if (want && tiles <= 65536 && g.L * g.lv[0].H <= 12288 && g.lv[0].W < 32768 && g.lv[0].H < 32768) {
             g.epi_rows = g.lv[0].H;
             g.epi_off = (g.row_tab_stride + 1) & ~1;
@@ -433,6 +431,42 @@ struct LanePool {
 };
 LanePool g_pool[16];
 
+// k_detect's spill arena (compact form) is shared by every handle of a device whose spill chunks have the same size - a left / right pair, the
+// handles of a bench or test process: the busy flags make it safe under concurrent kernels of any number of handles (a chunk is claimed with a
+// compare-and-swap and returned by the workgroup that took it), and its size depends on how many workgroups the DEVICE can hold, not on how many
+// handles exist.  Reference counted; the last handle frees it.  (Round-5 review: ~80 MB per handle before.)
+struct SpillArena { int device; int chunk_entries; unsigned *data; unsigned *flags; int refs; };
+std::mutex g_arena_mu;
+std::vector<SpillArena> g_arenas;
+
+int arena_acquire(jsorb_extractor *e, int chunk_entries, size_t bytes, size_t flag_words, unsigned **data, unsigned **flags)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (auto &a : g_arenas)
+        if (a.device == e->device && a.chunk_entries == chunk_entries) { a.refs++; *data = a.data; *flags = a.flags; return JSORB_OK; }
+    SpillArena a{e->device, chunk_entries, nullptr, nullptr, 1};
+    if (hipMalloc(&a.data, bytes) != hipSuccess) { (void)hipGetLastError(); return JSORB_ERR_HIP; }
+    if (hipMalloc(&a.flags, flag_words * sizeof(unsigned)) != hipSuccess || hipMemset(a.flags, 0, flag_words * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(a.data);
+        if (a.flags) (void)hipFree(a.flags);
+        return JSORB_ERR_HIP;
+    }
+    g_arenas.push_back(a);
+    *data = a.data; *flags = a.flags;
+    return JSORB_OK;
+}
+void arena_release(unsigned *data)
+{
+    if (!data) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (size_t i = 0; i < g_arenas.size(); i++)
+        if (g_arenas[i].data == data) {
+            if (--g_arenas[i].refs == 0) { (void)hipFree(g_arenas[i].data); (void)hipFree(g_arenas[i].flags); g_arenas.erase(g_arenas.begin() + i); }
+            return;
+        }
+}
+
 int pool_stream(jsorb_extractor *e, int j, hipStream_t *out)
 {
     LanePool &p = g_pool[e->device & 15];
@@ -452,7 +486,7 @@ int pool_copy_stream(jsorb_extractor *e, hipStream_t *out)
     if (!p.copy) {
         int least = 0, greatest = 0;
         HIPCHK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int prio = getenv("JSORB_COPY_PRIORITY") ? std::max(greatest, std::min(least, atoi(getenv("JSORB_COPY_PRIORITY")))) : greatest;
+        const int prio = experiment_env("JSORB_COPY_PRIORITY") ? std::max(greatest, std::min(least, atoi(experiment_env("JSORB_COPY_PRIORITY")))) : greatest;
         HIPCHK(e, hipStreamCreateWithPriority(&p.copy, hipStreamNonBlocking, prio));
     }
     *out = p.copy;
@@ -582,11 +616,8 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
     int rc;
     if (K == 1) ls[0] = e->stream;                  // one lane (single frame, small batch, per-kernel timing): the handle's main stream
     else
-        for (int j = 0; j < K; j++) {
+        for (int j = 0; j < K; j++)
             if ((rc = pool_stream(e, j, &ls[j]))) return rc;
-            if (e->stagger && j + 1 < K && !e->ev_stage[j][0])
-                for (int q = 0; q < 6; q++) HIPCHK(e, hipEventCreateWithFlags(&e->ev_stage[j][q], hipEventDisableTiming));
-        }
     if ((rc = order_lanes_for_new_batch(e, K, n, ls, input_ready))) return rc;
     const size_t T = (size_t)g.T;
     const int CW = JSORB_MAX_LEVELS + 1;
@@ -638,21 +669,13 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
                 capturing = true;
             }
         }
-        // Software pipeline across the lanes: stage s of lane j starts when stage s of lane j-1 has finished, so that at any time
-        // DIFFERENT stages are resident on the GPU (k_detect's sparse ring-test phases next to k_blur's FMA chains next to
-        // k_describe's gathers) instead of the same stage of all lanes competing for the same unit.
-        int stage = 0;
-#define JSORB_STAGE(id, launch_stmt)                                                                                        \
-        do {                                                                                                                \
-            if (e->stagger && j > 0) HIPCHK(e, hipStreamWaitEvent(st, e->ev_stage[j - 1][stage], 0));                       \
-            TIMED(e, id, launch_stmt);                                                                                      \
-            if (e->stagger && j + 1 < K) HIPCHK(e, hipEventRecord(e->ev_stage[j][stage], st));                              \
-            stage++;                                                                                                        \
-        } while (0)
+        // (a software pipeline across the lanes - stage s of lane j behind stage s of lane j-1 - was measured slower than free-running lanes: 77.8 k
+        // against 80 k pairs/s in round 2; removed in round 6)
+#define JSORB_STAGE(id, launch_stmt) TIMED(e, id, launch_stmt)
         if (e->upload_pending) launch_upload_level0(e->h_upload, e->stage[0], (size_t)g.lv[0].H * g.lv[0].W, st);
         JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
         // single image: k_detect and k_blur (independent of each other) as ONE launch - a frame is a chain of small launches whose latencies add up
-        static const bool fuse_env = !(getenv("JSORB_FUSED_DETECT_BLUR") && atoi(getenv("JSORB_FUSED_DETECT_BLUR")) == 0);
+        static const bool fuse_env = !env_is(experiment_env("JSORB_FUSED_DETECT_BLUR"), 0);
         const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0 && !g.det_compact && e->detect_lds + 12 * 1024 <= 64 * 1024;      // (k_blur's 10 KB of static LDS come on top of k_detect's request)
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
         else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st, e->det_spill, e->det_spill_flags));
@@ -759,7 +782,7 @@ void spec_after_extract(jsorb_extractor *e, int n)
     if (ok) {
         const StereoArgs sa = make_stereo_args(S->mb, S->mbf, S->th_high, S->th_low);
         launch_stereo(l->g, l->src, l->slab, r->src, r->slab, l->out_kp, l->counts, l->desc, r->out_kp, r->counts, r->desc, r->row_tab,
-                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st, nullptr, DeliverStereo{l->h_sp_u, l->h_sp_d, nullptr});
+                      l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, sa, 1, st, nullptr);
         launch_median(l->g, l->counts, l->sp_u, l->sp_d, l->sp_l1, l->sp_aux, l->sp_stats, 1, st, DeliverStereo{l->h_sp_u, l->h_sp_d, l->h_sp_stats});
         ok = hipGetLastError() == hipSuccess && hipEventRecord(S->ev_done, st) == hipSuccess;
         // whatever went out on the stream reads both handles' buffers: their next extracts are ordered after it in any case
@@ -836,11 +859,11 @@ int jsorb_create(const jsorb_params *params, const uint8_t *mask, jsorb_extracto
 }
 
 // host-only part of a handle's launch plan for k_detect (also behind jsorb_plan_launch)
-static void plan_detect(Geometry &g)
+static void plan_detect(Geometry &g, bool compact_possible = true)
 {
     for (int i = 0; i < g.L; i++) {                        // needed by the LDS layout: the arg-max form needs 256 B where the literal tree needs 1 KB
         uint8_t tr[256];
-        g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !getenv("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
+        g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !experiment_env("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
     }
     // Batch handles run k_detect's compact form (score plane built late, on top of the dead image tile; positives in an LDS pool that spills into a
     // borrowed chunk of global memory: 7 workgroups per CU instead of 4) when the tiles are small enough for bands of several tile rows - measured
@@ -848,9 +871,9 @@ static void plan_detect(Geometry &g)
     // -22 % / +2 %, but C2 with the "1000 features" tile 58 only -8 % / -6 % (one tile row per workgroup in either form, and the full-plane request
     // leaves a k_describe workgroup its place on every CU).  Single-image handles keep the full-plane form (one image does not fill the chip).
     // JSORB_DETECT_FULLPLANE=1 / 0 forces the full-plane / the compact form on a batch handle (A/B measurements, tests).
-    const char *force = getenv("JSORB_DETECT_FULLPLANE");
+    const char *force = product_env("JSORB_DETECT_FULLPLANE");
     const bool want_compact = force ? atoi(force) == 0 : g.lv[0].th <= 40;
-    g.det_compact = (!g.latency && want_compact) ? 1 : 0;
+    g.det_compact = (!g.latency && want_compact && compact_possible) ? 1 : 0;
     fill_detect_layout(g);
 }
 
@@ -902,16 +925,32 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
         HIPCHK(e, hipEventCreateWithFlags(&e->lane_done[j], hipEventDisableTiming));
         HIPCHK(e, hipEventCreateWithFlags(&e->lane_readers_done[j], hipEventDisableTiming));
     }
-    if (const char *ml = getenv("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));      // tuning hooks
-    if (const char *sg = getenv("JSORB_LANE_STAGGER")) e->stagger = atoi(sg);
-    if (const char *sw = getenv("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
-    if (const char *sp = getenv("JSORB_SPECULATE")) { e->speculate_env = atoi(sp) != 0; e->speculate = e->speculate_env; }
-    if (const char *ku = getenv("JSORB_KERNEL_UPLOAD")) e->kernel_upload = atoi(ku);
-    if (const char *hl = getenv("JSORB_HOST_LANES")) e->host_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(hl)));
-    if (const char *tr = getenv("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
-    if (const char *fg = getenv("JSORB_FRAME_GRAPH")) e->use_frame_graph = atoi(fg);
-    if (const char *mp = getenv("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
+    if (const char *ml = product_env("JSORB_MAX_LANES")) e->max_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(ml)));
+    if (const char *sw = experiment_env("JSORB_SPIN_WAIT")) e->spin_wait = atoi(sw);
+    if (const char *sp = product_env("JSORB_SPECULATE")) { e->speculate_env = atoi(sp) != 0; e->speculate = e->speculate_env; }
+    if (const char *ku = experiment_env("JSORB_KERNEL_UPLOAD")) e->kernel_upload = atoi(ku);
+    if (const char *hl = experiment_env("JSORB_HOST_LANES")) e->host_lanes = std::max(1, std::min(JSORB_MAX_LANES, atoi(hl)));
+    if (const char *tr = experiment_env("JSORB_TRACE_HOST")) e->trace_host = atoi(tr) != 0;
+    if (const char *fg = product_env("JSORB_FRAME_GRAPH")) e->use_frame_graph = atoi(fg);
+    if (const char *mp = product_env("JSORB_LANE_MIN_MPX")) e->lane_min_px = std::max(0.01, atof(mp)) * 1e6;
     plan_detect(g);
+    if (g.det_compact) {
+        // The compact form borrows spill chunks from a per-device arena laid out for 8 XCDs of at most 40 CUs.  Where that does not hold, or the arena
+        // cannot be allocated, the handle runs the full-plane form (which needs no global resource) - unless the compact form was asked for by name.
+        int cus = 0;
+        HIPCHK(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        const bool forced = env_is(product_env("JSORB_DETECT_FULLPLANE"), 0);
+        int arc = detect_arena_covers(cus) ? arena_acquire(e, detect_spill_chunk_entries(g), detect_arena_bytes(g), detect_arena_flag_words(), &e->det_spill, &e->det_spill_flags)
+                                           : JSORB_ERR_UNSUPPORTED;
+        if (arc != JSORB_OK) {
+            if (forced) {
+                e->err = arc == JSORB_ERR_UNSUPPORTED ? "JSORB_DETECT_FULLPLANE=0: k_detect's spill arena is laid out for 8 XCDs of at most 40 CUs, not for this device"
+                                                      : "JSORB_DETECT_FULLPLANE=0: k_detect's spill arena could not be allocated";
+                return arc;
+            }
+            plan_detect(g, false);
+        }
+    }
     e->detect_lds = detect_lds_bytes(g);
     if (e->detect_lds > 160 * 1024) { e->err = "tile too large for LDS"; return JSORB_ERR_INVALID; }
     // LDS partition of a CU in the batch pipeline (profiles/r04_lds_counters.txt, "LDS request sweep"): the lanes overlap k_detect of one image
@@ -922,12 +961,11 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     {
         hipFuncAttributes fa{};
         const size_t cu_lds = 160 * 1024, gran = 1280;
-        if (!g.det_compact && hipFuncGetAttributes(&fa, describe_kernel_address()) == hipSuccess && !getenv("JSORB_DETECT_LDS_NATURAL")) {
+        if (!g.det_compact && hipFuncGetAttributes(&fa, describe_kernel_address()) == hipSuccess) {
             const size_t desc = (fa.sharedSizeBytes + gran - 1) / gran * gran;
             const size_t want = desc < cu_lds ? (cu_lds - desc) / 4 / gran * gran : 0;
             if (e->detect_lds <= want) e->detect_lds = want;
         }
-        if (const char *rq = getenv("JSORB_DETECT_LDS_REQUEST")) e->detect_lds = std::max(detect_lds_bytes(g), (size_t)atoi(rq));      // experiment hook: explicit request (never below what the layout needs)
     }
     e->pyr_lds = pyramid_lds_bytes(g);
     for (int i = 1; i < g.L; i++)
@@ -949,14 +987,6 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
     }
     HIPCHK(e, hipMalloc(&e->lut_bits, (2048 + (size_t)g.detect_blocks + g.blur_blocks + g.pyr_blocks + 64 * JSORB_MAX_LEVELS) * sizeof(uint32_t)));      // arc LUT + workgroup tables + tree priorities
     HIPCHK(e, hipMalloc(&e->tile_out, B * T * 8));
-    if (g.det_compact) {
-        int cus = 0;
-        HIPCHK(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-        if (!detect_arena_covers(cus)) { e->err = "k_detect's spill arena is laid out for 8 XCDs of at most 32 CUs: set JSORB_DETECT_FULLPLANE=1 on this device"; return JSORB_ERR_UNSUPPORTED; }
-        HIPCHK(e, hipMalloc(&e->det_spill, detect_arena_bytes(g)));
-        HIPCHK(e, hipMalloc(&e->det_spill_flags, detect_arena_flag_words() * sizeof(unsigned)));
-        HIPCHK(e, hipMemset(e->det_spill_flags, 0, detect_arena_flag_words() * sizeof(unsigned)));
-    }
     HIPCHK(e, hipMalloc(&e->kp, B * T * 8));
     HIPCHK(e, hipMalloc(&e->counts, B * (JSORB_MAX_LEVELS + 1) * sizeof(int)));
     HIPCHK(e, hipMalloc(&e->row_tab, B * (size_t)g.row_tab_stride * sizeof(int)));
@@ -1070,9 +1100,10 @@ void jsorb_destroy(jsorb_extractor *e)
         if (e->lane_used[j]) (void)hipStreamSynchronize(e->lane_used[j]);
     for (auto &t : e->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *bufs[] = {e->stage[0], e->stage[1], e->slab, e->blur, e->mask, e->lut_bits, e->tile_out, e->kp, e->counts, e->row_tab, e->angles, e->desc,
-                    e->out_kp, e->det_spill, e->det_spill_flags, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
+                    e->out_kp, e->st_u, e->st_d, e->st_l1, e->st_stats, e->st_aux, e->st_diag, e->sp_u, e->sp_d, e->sp_stats, e->sp_l1, e->sp_aux, e->ms_grid, e->ms_scratch, e->frame_aos, e->grid_start, e->grid_items};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    arena_release(e->det_spill);      // (every kernel of this handle has finished: the lanes were synchronised above)
     if (e->h_counts) (void)hipHostFree(e->h_counts);
     for (void *hp : {(void *)e->h_kp, (void *)e->h_desc, (void *)e->h_u, (void *)e->h_d, (void *)e->h_sp_u, (void *)e->h_sp_d, (void *)e->h_sp_stats, (void *)e->h_upload})
         if (hp) (void)hipHostFree(hp);
@@ -1081,8 +1112,6 @@ void jsorb_destroy(jsorb_extractor *e)
     for (int j = 0; j < JSORB_MAX_LANES; j++) {
         if (e->lane_done[j]) (void)hipEventDestroy(e->lane_done[j]);
         if (e->lane_readers_done[j]) (void)hipEventDestroy(e->lane_readers_done[j]);
-        for (int q = 0; q < 6; q++)
-            if (e->ev_stage[j][q]) (void)hipEventDestroy(e->ev_stage[j][q]);
     }
     for (int k = 0; k < 2; k++) {
         for (int j = 0; j < JSORB_MAX_LANES; j++) {
@@ -1274,7 +1303,7 @@ static int extract_batch_device_enqueue(jsorb_extractor *e, const uint8_t *dev_i
     // KITTI-shaped configuration's kernel time).  Every 16-byte chunk a kernel samples lies inside its row; chunks that cross the end of a
     // row are zero-filled (k_detect, k_blur: never sampled), bounds-checked (k_pyramid) or continue into the next row of the same image
     // (k_describe, k_stereo: rows at least 5 above the last).  JSORB_COPY_UNALIGNED=1 restores the copy.
-    static const bool copy_unaligned = getenv("JSORB_COPY_UNALIGNED") && atoi(getenv("JSORB_COPY_UNALIGNED")) != 0;
+    static const bool copy_unaligned = experiment_env("JSORB_COPY_UNALIGNED") && atoi(experiment_env("JSORB_COPY_UNALIGNED")) != 0;
     const bool aligned16 = (step % 16 == 0) && (((uintptr_t)dev_images) % 16 == 0) && (image_stride % 16 == 0);
     const bool in_place = aligned16 || !copy_unaligned;
     if (in_place) {   // no copy of the grayscale plane
@@ -1563,8 +1592,7 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
                                               l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_stride,
                                               l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T, sa, m, st,
-                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr,
-                                              direct ? DeliverStereo{l->h_u, l->h_d, nullptr} : DeliverStereo{nullptr, nullptr, nullptr}));
+                                              l->st_diag ? l->st_diag + f * T * JSORB_STEREO_DIAG_INTS : nullptr));
         TIMED(l, JSORB_K_MEDIAN, launch_median(l->g, l->counts + f * CW, l->st_u + f * T, l->st_d + f * T, l->st_l1 + f * T, l->st_aux + f * T,
                                               l->st_stats + f * 8, m, st, direct ? DeliverStereo{l->h_u, l->h_d, l->h_stats} : DeliverStereo{nullptr, nullptr, l->h_stats + f * 8}));
         HIPCHK(l, hipGetLastError());

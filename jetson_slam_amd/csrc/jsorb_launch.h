@@ -6,6 +6,7 @@
 
 #include "../../include/jsorb.h"
 #include "jsorb_device.h"
+#include "jsorb_env.h"
 
 namespace jsorb {
 
@@ -53,8 +54,7 @@ int describe_kernel_deliver_arg();         // index of its `Deliver dl` argument
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
-                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag = nullptr,
-                   DeliverStereo dl2 = DeliverStereo{nullptr, nullptr, nullptr});      // dl2: only read by the -DSTEREO_TWO_WRITER experiment build
+                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag = nullptr);
 #define JSORB_STEREO_DIAG_INTS 13          // per left keypoint: best right index, its Hamming distance, 11 L1 window sums (jsorb_copy_stereo_diagnostics)
 void launch_unpack_keypoints(const int32_t *soa, int n, jsorb_keypoint *out, hipStream_t s);
 void launch_assign_grid(const int32_t *soa, int n, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,

@@ -37,7 +37,7 @@ void fill_blur_layout(Geometry &g)
         // batch handles: BLUR_RB_BATCH rows, and up to BLUR_RB_MAX on the BLUR_TALL_LEVELS largest levels (6 halo rows per band: 37 % more conversions and
         // horizontal sums at 16 rows, 19 % at 32 - but a launch of 32-row bands everywhere ended in a long thin tail: 117.2 k against 120.0 k pairs/s)
         const int rb_batch = i < BLUR_TALL_LEVELS ? BLUR_RB_TALL : BLUR_RB_BATCH;
-        const int rb_max = getenv("JSORB_BLUR_ROWS") ? std::max(1, std::min(BLUR_RB_MAX, atoi(getenv("JSORB_BLUR_ROWS")))) : (g.latency ? 8 : rb_batch);
+        const int rb_max = experiment_env("JSORB_BLUR_ROWS") ? std::max(1, std::min(BLUR_RB_MAX, atoi(experiment_env("JSORB_BLUR_ROWS")))) : (g.latency ? 8 : rb_batch);
         const int nrb = (rh + rb_max - 1) / rb_max;
         lv.blur_bx = ncs;                                   // strips per band
         lv.blur_by = nrb;                                   // bands

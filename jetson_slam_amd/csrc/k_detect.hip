@@ -175,7 +175,7 @@ void fill_detect_layout(Geometry &g)
     // end of round 3 (pairs/s at C2 / C3 / C5): 7 workgroups per CU (the round-2 choice) 107.1 / 80.6 / 30.8 k, 6: 109.7 / 84.9 / 31.7 k,
     // 5: 111.7 / 85.5 / 32.0-32.3 k, 4: 109.5 / 85.7 / 31.6 k.
     // Compact form (round 5): the same band heights cost ~22 KB with a pool for >= 10 % positives: the budget is 18 granules - 7 workgroups = 7 waves per SIMD.
-    if (const char *b7 = getenv("JSORB_DETECT_BUDGET")) budget = std::max(budget, (size_t)atoi(b7));
+    if (const char *b7 = experiment_env("JSORB_DETECT_BUDGET")) budget = std::max(budget, (size_t)atoi(b7));
     else budget = std::max(budget, cp ? (size_t)DET_CP_BUDGET : (size_t)(160 * 1024 / 5 - 256));
     int dblk = 0;
     for (int i = 0; i < g.L; i++) {
@@ -183,7 +183,7 @@ void fill_detect_layout(Geometry &g)
         int R = 1;
         // only the arg-max form of the tile reduction (tree_rank_ok) handles several tile rows; keys: R * k_tiles <= 128 slots, row index < 256
         while (lv.tree_rank_ok && R < DET_MAX_R && R < lv.nth && (R + 1) * lv.k_tiles <= 128 && (R + 1) * lv.th + 2 <= 255 &&
-               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1, cp, 0).total <= budget && !getenv("JSORB_DETECT_NO_BANDS") && !g.latency)      // single-image handles: one tile row per workgroup
+               detect_lds_layout((R + 1) * lv.th, lv.tw, lv.k_tiles, 1, cp, 0).total <= budget && !experiment_env("JSORB_DETECT_NO_BANDS") && !g.latency)      // single-image handles: one tile row per workgroup
             R++;
         lv.det_R = R;
         lv.detect_blk0 = dblk;
@@ -219,7 +219,9 @@ int detect_spill_chunk_entries(const Geometry &g)
 size_t detect_arena_bytes(const Geometry &g) { return (size_t)DET_ARENA_XCDS * DET_ARENA_SLOTS * detect_spill_chunk_entries(g) * sizeof(unsigned); }
 size_t detect_arena_flag_words() { return (size_t)DET_ARENA_XCDS * DET_ARENA_SLOTS; }
 // workgroups of the compact k_detect that may be resident at once on this many CUs (4 waves each, 32 wave slots per CU) must not exceed the arena's chunks
-bool detect_arena_covers(int compute_units) { return (long)compute_units * 8 <= (long)DET_ARENA_XCDS * DET_ARENA_SLOTS && compute_units <= 32 * DET_ARENA_XCDS; }
+// (an XCD of a gfx942 / gfx950 part has at most 40 CUs, 32-38 of them active, whatever the partition mode: 40 x 8 resident workgroups = the 320 slots of
+// an XCD's partition; a device that reports more CUs than 8 such XCDs hold is not one this layout was made for)
+bool detect_arena_covers(int compute_units) { return compute_units >= 1 && compute_units <= DET_ARENA_XCDS * (DET_ARENA_SLOTS / 8); }
 int detect_pos_cap(const Geometry &g, int level) { return g.lv[level].det_pos_cap; }
 
 // Early rejects on 6-bit pixels (k_detect phase 1, SWAR form): with q(x) = x >> 2 and t4 = (th + 1) >> 2,
@@ -231,7 +233,7 @@ int detect_pos_cap(const Geometry &g, int level) { return g.lv[level].det_pos_ca
 int detect_swar6_threshold(int threshold)
 {
     const int thc = std::min(threshold, 256), t4 = (thc + 1) >> 2;
-    if (t4 < 2 || getenv("JSORB_DETECT_EXACT_REJECT")) return 0;
+    if (t4 < 2 || experiment_env("JSORB_DETECT_EXACT_REJECT")) return 0;
     const int cb = 128 - t4;
     for (int v = 0; v < 256; v++)
         for (int p = 0; p < 256; p++) {
@@ -279,6 +281,9 @@ extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
 // on the workgroup), publish it in the workgroup's LDS word; if another wave of the workgroup was faster, give the chunk back and take that one.
 // Returns chunk index + 1.  Deliberately NOT inlined: the probing loop sits in the middle of the ring pass, where the scalar registers are scarce -
 // inlined, the kernel went from 82 to 106 SGPRs and its hot loops reloaded kernel arguments (k_detect 215 -> 247 us per 128 images).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "k_detect's spill arena reads HW_REG_XCC_ID (hwreg 20): gfx942 / gfx950 only"
+#endif
 __device__ __attribute__((noinline)) unsigned detect_claim_chunk(unsigned *spill_flags, unsigned *s_chunk, unsigned blk, unsigned b)
 {
     unsigned ch = __hip_atomic_load(s_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -286,11 +291,18 @@ __device__ __attribute__((noinline)) unsigned detect_claim_chunk(unsigned *spill
     const unsigned xcc = __builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & (DET_ARENA_XCDS - 1);      // HW_REG_XCC_ID[3:0]
     unsigned *const fl = spill_flags + xcc * DET_ARENA_SLOTS;
     unsigned slot = (blk * 2654435761u + b * 40503u) % DET_ARENA_SLOTS;
-    int tries = 0;
+    int tries = 0, sweeps = 0;
 #pragma clang loop unroll(disable)
     while (atomicCAS(fl + slot, 0u, 1u) != 0u) {
         slot = slot + 1 == DET_ARENA_SLOTS ? 0 : slot + 1;
-        if (++tries > 8 * DET_ARENA_SLOTS) __builtin_trap();      // cannot happen (more slots than resident workgroups): fail loudly rather than hang
+        if (++tries == DET_ARENA_SLOTS) {
+            // A whole sweep without a free chunk: more holders than the partition has slots.  That takes workgroups parked with their chunks (the driver
+            // context-saved their waves under queue oversubscription) or a test build with a handful of slots: back off and keep probing - every holder gives
+            // its chunk back at the end of its NMS.  Only a partition that stays full for about a second (flags corrupted) ends the kernel loudly.
+            tries = 0;
+            __builtin_amdgcn_s_sleep(127);
+            if (++sweeps > 4096) __builtin_trap();
+        }
     }
     const unsigned mine = xcc * DET_ARENA_SLOTS + slot + 1u;
     const unsigned old = atomicCAS(s_chunk, 0u, mine);
@@ -377,9 +389,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     __syncthreads();
     DET_T(t_p1);
     DET_TACC(0, 0ull, 1ull); DET_TACC(1, t_start, t_staged); DET_TACC(2, t_staged, t_p1);
-#if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 1
-    if (tile_out) return;
-#endif
 
     // ---- phase 1: the two early rejects on every pixel of the (th+2) x (ktw+2) score region, 4 pixels per lane ----
     // LDS column c <-> image x = xs + c ; region column rx <-> c = c0 + rx.  A lane owns one aligned LDS dword (4 pixels)
@@ -539,11 +548,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         if (rb_first < rb_min) rb_first += ((rb_min - rb_first + step_rows - 1) >> sh) << sh;
     }
     const int rb_end = min(L.score_rows, H - JSORB_BORDER - (y0 - 1));               // rbase < rb_end: the region and the image's interior
-#if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 2
-#define DET_RING_PASS(last) do { n_mine = 0; } while (0)
-#else
 #define DET_RING_PASS(last) ring_pass(last)
-#endif
     int e_cur = (rb_first << 8) + e_lane;                  // list entry of the lane's first pixel in the current step
     for (int rbase = rb_first; rbase < rb_end; rbase += step_rows) {
         if (n_mine > flush_at) DET_RING_PASS(false);
@@ -656,9 +661,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     __syncthreads();
     DET_T(t_p3);
     DET_TACC(5, t_p2, t_p3);
-#if defined(DET_KNOCKOUT) && (DET_KNOCKOUT == 2 || DET_KNOCKOUT == 3)
-    if (tile_out) return;
-#endif
     int n_all = 0;                                        // compact form: positives of the band (pool + spill chunk)
     const unsigned *spill_chunk = nullptr;
     if constexpr (CP) {
@@ -757,9 +759,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     }
     DET_T(t_p4);
     DET_TACC(6, t_plane, t_p3e); DET_TACC(7, t_p3e, t_p4);
-#if defined(DET_KNOCKOUT) && DET_KNOCKOUT == 4
-    if (tile_out) return;
-#endif
 
     if (ranked) {
         // ---- phase 4 (arg-max form): one thread per tile decodes the winner ----

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
                                                const int *__restrict__ row_tabR,
                                                float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ best_l1,
-                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag, int npass, DeliverStereo dl2)
+                                               unsigned *__restrict__ aux, StereoArgs sa, int n_pairs, int *__restrict__ diag, int npass)
 {
     __shared__ int s_lvi[JSORB_MAX_LEVELS][12];      // th, nth, row_tab_off, W, pitch, img_off, 1/th magic, tw, ntw, tile_off, 1/tw magic (per level, lane-indexable)
     __shared__ float s_lvf[JSORB_MAX_LEVELS][2];     // scale, inv_scale
@@ -467,12 +467,6 @@ __global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const 
         u_right[tb + i] = out_u;
         depth[tb + i] = out_d;
         best_l1[tb + i] = out_l1;
-#ifdef STEREO_TWO_WRITER
-        // EXPERIMENT BUILD ONLY (round 5, the round-4 review's item 5): the delivery that was dropped in round 4 after one unexplained failure of the GPU suite -
-        // single-pair call: uRight / depth go to the pinned host mirror from HERE, k_median then only overwrites what its cut removes: two kernels store to
-        // the same pinned word and rely on the order of posted PCIe writes of different kernels
-        if (dl2.u_host) { dl2.u_host[i] = out_u; dl2.d_host[i] = out_d; }
-#endif
         // per-keypoint statistics; k_median reduces them per pair (per-wave global atomics on one cache line per pair
         // serialised at the L2 atomic unit and cost more than the whole matcher)
         aux[tb + i] = (n_cand & 0x7FFFFFFF) | (corr ? 0x80000000u : 0u);
@@ -666,11 +660,7 @@ __global__ __launch_bounds__(256) void k_median(Geometry g, const int *__restric
             depth[tb + i] = -1.0f;
             removed++;
         }
-#ifdef STEREO_TWO_WRITER
-        if (dl.u_host && cut) { dl.u_host[i] = -1.0f; dl.d_host[i] = -1.0f; }      // (k_stereo delivered the values)
-#else
-        if (dl.u_host && i < Nl) { dl.u_host[i] = cut ? -1.0f : uu[r]; dl.d_host[i] = cut ? -1.0f : zz[r]; }
-#endif
+        if (dl.u_host && i < Nl) { dl.u_host[i] = cut ? -1.0f : uu[r]; dl.d_host[i] = cut ? -1.0f : zz[r]; }      // ONE writer per pinned host word (a two-writer delivery was measured and dropped: profiles/r05_two_writer.txt)
     }
     if (removed) atomicAdd(&sm.s_removed, removed);
     __syncthreads();
@@ -699,7 +689,7 @@ void launch_gather_counts(const int *countsL, const int *countsR, const int *sta
 void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL, const ImageSrc &srcR, const uint8_t *slabR,
                    const int32_t *outL, const int *countsL, const uint8_t *descL,
                    const int32_t *outR, const int *countsR, const uint8_t *descR, const int *row_tabR,
-                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag, DeliverStereo dl2)
+                   float *u_right, float *depth, int *best_l1, unsigned *aux, StereoArgs a, int n_pairs, hipStream_t s, int *diag)
 {
     // Passes of four left keypoints per wave.  More passes = fewer instructions per keypoint (phases A2 and C once per wave, fuller task lists in
     // phase B), but a wave runs its passes one after the other and each pass is a chain of dependent loads: the launch must still consist of
@@ -707,14 +697,14 @@ void launch_stereo(const Geometry &g, const ImageSrc &srcL, const uint8_t *slabL
     // a single pair 1 - a frame waits for this kernel.  Measured, pairs/s of the whole pipeline on one box with 8 / 6 / 4 / 2 passes:
     // C2 123.7 / 123.7 / 122.5 / 121.7 k (round-4 kernel before this one: 121.0 k); k_stereo alone per step C2 101 / 103 / 102 / 112 us,
     // C3 (before the batched candidate loads) 105 / 98 / 97 / 101 us, C5 359 / 354 / 364 / 393 us.
-    static const int env_pass = getenv("JSORB_STEREO_PASSES") ? std::max(1, std::min(ST_MAX_PASS, atoi(getenv("JSORB_STEREO_PASSES")))) : 0;
+    static const int env_pass = experiment_env("JSORB_STEREO_PASSES") ? std::max(1, std::min(ST_MAX_PASS, atoi(experiment_env("JSORB_STEREO_PASSES")))) : 0;
     auto waves = [&](int np) { return (long)n_pairs * ((g.T + SKPW * np - 1) / (SKPW * np)); };
     int npass = 1;
     if (env_pass) npass = env_pass;
     else if (n_pairs > 1) npass = waves(8) >= 24576 ? 8 : waves(6) >= 12288 ? 6 : waves(4) >= 12288 ? 4 : waves(2) >= 12288 ? 2 : 1;
     const int kpw = SKPW * npass;
     hipLaunchKernelGGL(k_stereo, xcd_grid((g.T + kpw - 1) / kpw, n_pairs), dim3(64), 0, s, g, srcL, slabL, srcR, slabR, outL, countsL, descL,
-                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, npass, dl2);
+                       outR, countsR, descR, row_tabR, u_right, depth, best_l1, aux, a, n_pairs, diag, npass);
 }
 
 void launch_median(const Geometry &g, const int *countsL, float *u_right, float *depth, const int *best_l1, const unsigned *aux,

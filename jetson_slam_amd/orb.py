@@ -62,14 +62,22 @@ class JsorbError(RuntimeError):
 
 
 _lib = None
+_libs_by_path = {}
 
 
 def load_library(path=None):
-    """dlopen libjsorb.so (the in-tree build).  Raises if it has not been built: there is no fallback path."""
+    """dlopen libjsorb.so (the in-tree build).  Raises if it has not been built: there is no fallback path.
+    With an explicit path: another build of the same ABI (jetson_slam_amd/build.py VARIANTS), loaded next to the default one and returned
+    without replacing it - tests that need it swap the module's `_lib` for their duration."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    explicit = path is not None
     path = path or os.environ.get("JSORB_LIBRARY") or _LIB_PATH      # JSORB_LIBRARY: an alternative build of the same ABI
+    if path in _libs_by_path:
+        if not explicit:
+            _lib = _libs_by_path[path]
+        return _libs_by_path[path]
     if not os.path.exists(path):
         raise JsorbError("%s not found - run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % path)
     lib = C.CDLL(path)
@@ -134,7 +142,9 @@ def load_library(path=None):
     for name, (rt, at) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = rt, at
-    _lib = lib
+    _libs_by_path[path] = lib
+    if not explicit:
+        _lib = lib
     return lib
 
 

@@ -69,15 +69,77 @@ def _noise(seed, stream, height, width, amp):
     return _uniform_int(u, -amp, amp).astype(np.int16).reshape(height, width)
 
 
-def synth_stereo_pair(seed, height=480, width=752):
-    """Return (left, right) uint8 images of shape (height, width)."""
-    clean = _clean_left(seed, height, width)
-    left = np.clip(clean + _noise(seed, 3, height, width, 3), 0, 255).astype(np.uint8)
+def _pair_from_clean(clean, seed, height, width, amp_left=3, amp_right=2):
+    """(left, right) from a noise-free left image: left = clean + U[-amp_left, amp_left]; right = clean shifted by the row-dependent integer
+    disparity d(y) = 6 + floor(24 y / H) (edge replicated) + U[-amp_right, amp_right]."""
+    left = np.clip(clean + (_noise(seed, 3, height, width, amp_left) if amp_left else 0), 0, 255).astype(np.uint8)
     d = 6 + (24 * np.arange(height)) // height
     cols = np.minimum(np.arange(width)[None, :] + d[:, None], width - 1)
     shifted = np.take_along_axis(clean, cols, axis=1)
-    right = np.clip(shifted + _noise(seed, 4, height, width, 2), 0, 255).astype(np.uint8)
+    right = np.clip(shifted + (_noise(seed, 4, height, width, amp_right) if amp_right else 0), 0, 255).astype(np.uint8)
     return left, right
+
+
+def synth_stereo_pair(seed, height=480, width=752):
+    """Return (left, right) uint8 images of shape (height, width)."""
+    return _pair_from_clean(_clean_left(seed, height, width), seed, height, width)
+
+
+# ---- other image statistics (bench.py `other_inputs`, tests): the kernels' list / pool / spill sizes were tuned on synth_stereo_pair only ----
+INPUT_FAMILIES = ("noise", "saltpepper", "lowtexture", "natural")
+
+
+def _value_noise(seed, stream, height, width, octave):
+    """integer value noise: U[0, 255] on a lattice of spacing 2^octave, bilinearly interpolated with exact integer weights; returns values * 4^octave"""
+    s = 1 << octave
+    gh, gw = height // s + 2, width // s + 2
+    lat = _uniform_int(_stream(seed, stream, gh * gw), 0, 255).reshape(gh, gw)
+    y, x = np.arange(height), np.arange(width)
+    y0, fy = y >> octave, y & (s - 1)
+    x0, fx = x >> octave, x & (s - 1)
+    a = lat[y0][:, x0] * (s - fx)[None, :] + lat[y0][:, x0 + 1] * fx[None, :]
+    b = lat[y0 + 1][:, x0] * (s - fx)[None, :] + lat[y0 + 1][:, x0 + 1] * fx[None, :]
+    return a * (s - fy)[:, None] + b * fy[:, None]
+
+
+def synth_family_pair(kind, seed, height=480, width=752):
+    """Stereo pairs with other statistics than synth_stereo_pair (same disparity model, integer arithmetic only - reproducible anywhere):
+      noise       every pixel U[0, 255]: nearly every pixel passes the early rejects, a fifth of them are FAST corners - every band of k_detect spills
+      saltpepper  mid grey 128 with 25 % of the pixels set to 0 or 255 (isolated extreme pixels: the densest corner field an image can hold)
+      lowtexture  flat grey + U[-1, 1] noise with half a dozen rectangles: ~100 keypoints per image, nearly every tile empty
+      natural     a 1/f-like field: seven octaves of integer value noise, amplitude proportional to the lattice spacing, + U[-2, 2] noise"""
+    if kind == "noise":
+        clean = _uniform_int(_stream(seed, 11, height * width), 0, 255).astype(np.int16).reshape(height, width)
+        return _pair_from_clean(clean, seed, height, width, 0, 2)
+    if kind == "saltpepper":
+        u = _stream(seed, 12, height * width)
+        sel = (u % np.uint64(8)).reshape(height, width)
+        clean = np.full((height, width), 128, np.int16)
+        clean[sel == 0] = 0
+        clean[sel == 1] = 255
+        return _pair_from_clean(clean, seed, height, width, 2, 2)
+    if kind == "lowtexture":
+        clean = np.full((height, width), 120, np.int16)
+        area = height * width
+        n_rect = max(3, int(round(6.0 * area / (752.0 * 480.0))))
+        u = _stream(seed, 13, 5 * n_rect)
+        rw, rh = _uniform_int(u[0::5], 20, 90), _uniform_int(u[1::5], 20, 90)
+        rx, ry = _uniform_int(u[2::5], 30, max(30, width - 120)), _uniform_int(u[3::5], 30, max(30, height - 120))
+        rv = _uniform_int(u[4::5], 0, 255)
+        for k in range(n_rect):
+            clean[int(ry[k]):int(ry[k] + rh[k]), int(rx[k]):int(rx[k] + rw[k])] = rv[k]
+        return _pair_from_clean(clean, seed, height, width, 1, 1)
+    if kind == "natural":
+        acc = np.zeros((height, width), np.int64)
+        wsum = 0
+        for o in range(7):
+            # amplitude ~ lattice spacing (1/f): value noise of octave o comes scaled by 4^o; bring every octave to a common 2^12 scale, weight 2^o
+            acc += (_value_noise(seed, 20 + o, height, width, o) << (12 - 2 * o)) * (1 << o)
+            wsum += 1 << o
+        mean = (acc // wsum) >> 12                                                 # 0..255, heavily averaged towards 128
+        clean = np.clip((mean - 128) * 3 + 128, 0, 255).astype(np.int16)            # stretch the contrast back
+        return _pair_from_clean(clean, seed, height, width, 2, 2)
+    raise ValueError("unknown input family %r" % (kind,))
 
 
 def synth_image(seed, height=480, width=752):

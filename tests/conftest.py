@@ -35,6 +35,17 @@ def orb():
     return _orb
 
 
+@pytest.fixture
+def experiments_lib(orb, monkeypatch):
+    """The `experiments` variant build (every translation unit with -DJSORB_EXPERIMENTS, csrc/jsorb_env.h) as the library behind `orb` for the
+    duration of one test: the switches that force launch layouts and fallback kernel paths by hand exist only there - the shipped library
+    never reads them."""
+    from jetson_slam_amd import build as jb
+    lib = orb.load_library(jb.build_variant("experiments", *jb.VARIANTS["experiments"]))
+    monkeypatch.setattr(orb, "_lib", lib)
+    return lib
+
+
 CONFIGS = {
     # name: dict(h, w, L, tile, th, fx, bf)  - SURVEY.md 8(d)
     "tiny": dict(h=120, w=160, L=4, tile=12, th=20, fx=200.0, bf=20.0),

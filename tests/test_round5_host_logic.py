@@ -74,10 +74,13 @@ def test_compact_detect_layout(orb, name, monkeypatch):
 
 
 def test_fullplane_knob_and_budget_knob_are_honoured():
-    """JSORB_DETECT_FULLPLANE=1 / 0 forces the full-plane / compact form on a batch handle; JSORB_DETECT_BUDGET raises the LDS budget the bands are chosen for."""
+    """JSORB_DETECT_FULLPLANE=1 / 0 forces the full-plane / compact form on a batch handle; JSORB_DETECT_BUDGET (experiments build only) raises the LDS budget the bands are chosen for."""
     code = ("import sys; sys.path.insert(0, %r)\nfrom jetson_slam_amd import orb\np = orb.plan_launch(480, 752, 1.2, 8, 30, 30, max_batch=64)\n"
             "print(p['compact'], p['detect_lds'], p['detect_blocks'])") % ROOT
     def run(env):
+        if "JSORB_DETECT_BUDGET" in env:      # an experiment switch: only the `experiments` variant build reads it (csrc/jsorb_env.h)
+            from jetson_slam_amd import build as jb
+            env = dict(env, JSORB_LIBRARY=jb.build_variant("experiments", *jb.VARIANTS["experiments"]))
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-800:]
         return [int(v) for v in r.stdout.split()]

@@ -87,7 +87,7 @@ int main(int argc, char **argv)
         if (a != 0) { fprintf(stderr, "the reference handles adopted a speculative match\n"); return 5; }
     }
     double t_ext = 0, t_cpu = 0, t_st = 0, t_unp = 0;
-    std::vector<double> per_frame;
+    std::vector<double> per_frame, spawn_us;
     for (int it = -20; it < frames; it++) {
         const int pair = (it + 20) % n_pairs;
         const size_t off = img_bytes * (size_t)pair;
@@ -119,7 +119,11 @@ int main(int argc, char **argv)
                 return 4;
             }
         }
-        if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; per_frame.push_back(t3 - t0); }
+        // what the reference's code shape spends on std::thread alone: two no-op threads spawned and joined, timed in the same loop (outside the frame's time)
+        const double s0 = now_us();
+        { std::thread ta([] {}); std::thread tb([] {}); ta.join(); tb.join(); }
+        const double s1 = now_us();
+        if (it >= 0) { t_ext += t1 - t0; t_cpu += t2 - t1; t_st += t3 - t2; t_unp += t4 - t3; per_frame.push_back(t3 - t0); spawn_us.push_back(s1 - s0); }
     }
     quit.store(true);
     for (auto &t : workers) t.join();
@@ -138,14 +142,16 @@ int main(int argc, char **argv)
                       memcmp(u_ref.data(), u_spec.data(), u_ref.size() * sizeof(float)) == 0 && memcmp(d_ref.data(), d_spec.data(), d_ref.size() * sizeof(float)) == 0;
     if (!same) { fprintf(stderr, "speculative and plain stereo results differ\n"); return 3; }
     std::sort(per_frame.begin(), per_frame.end());
+    std::sort(spawn_us.begin(), spawn_us.end());
     const double med = per_frame.empty() ? 0.0 : per_frame[per_frame.size() / 2], p90 = per_frame.empty() ? 0.0 : per_frame[per_frame.size() * 9 / 10];
+    const double p10 = per_frame.empty() ? 0.0 : per_frame[per_frame.size() / 10], spawn_med = spawn_us.empty() ? 0.0 : spawn_us[spawn_us.size() / 2];
     if (getenv("JSORB_JSON"))
-        printf("{\"frames\": %d, \"pairs_rotated\": %d, \"total_us_median\": %.1f, \"total_us_p90\": %.1f, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
-               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames, n_pairs, med, p90,
+        printf("{\"frames\": %d, \"pairs_rotated\": %d, \"total_us_median\": %.1f, \"total_us_p10\": %.1f, \"total_us_p90\": %.1f, \"thread_spawn_us\": %.1f, \"extract_lr_us\": %.1f, \"to_cpu_x4_us\": %.1f, \"stereo_us\": %.1f, \"total_us\": %.1f, \"unpack_x2_us\": %.1f, "
+               "\"speculative_matches_adopted\": %ld, \"speculative_matches_dropped\": %ld, \"same_bits_without_speculation\": true}\n", frames, n_pairs, med, p10, p90, spawn_med,
                t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped);
     else
     printf("per frame (us): extract L||R (2 threads) %.1f, 4x to_cpu %.1f, ComputeStereoMatches %.1f  => %.1f total ; UnpackFrame x2 instead of to_cpu: %.1f ; "
-           "speculative matches adopted %ld / dropped %ld ; median %.1f, p90 %.1f\n",
-           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped, med, p90);
+           "speculative matches adopted %ld / dropped %ld ; median %.1f, p10 %.1f, p90 %.1f ; two no-op std::threads spawn + join %.1f\n",
+           t_ext / frames, t_cpu / frames, t_st / frames, (t_ext + t_cpu + t_st) / frames, t_unp / frames, adopted, dropped, med, p10, p90, spawn_med);
     return 0;
 }
