@@ -104,6 +104,53 @@ def cpu_baseline(cfg, lefts, rights, budget_s=12.0):
                       "oracle built -O3 -march=native=%s" % (n, len(lefts), t, cores, native)}
 
 
+def multi_self_check(per_rank, single_device=False, gloo=False):
+    """What the first real multi-GPU record has to explain by itself (round-5 review): every rank on its OWN device (device index and PCI address
+    differ), every rank bound to its GPU's NUMA node, the one collective cheap (mean all_gather < 100 us over RCCL), and no straggler (a rank whose
+    median block exceeds the fastest rank's by more than 5 % is named with what sets it apart).  Returns {"ok": bool, "checks": {...}, "diagnosis": str}.
+    Pure function of the gathered per-rank records: tests/test_round6_host_logic.py feeds it hand-made ones."""
+    n = len(per_rank)
+    checks, notes = {}, []
+    if single_device:
+        checks["distinct_devices"] = checks["distinct_pci"] = "skipped (JSORB_BENCH_SINGLE_DEVICE test hook: every rank on cuda:0)"
+    else:
+        checks["distinct_devices"] = len({r["device_index"] for r in per_rank}) == n
+        checks["distinct_pci"] = len({r["pci"] for r in per_rank}) == n
+        if checks["distinct_devices"] is not True:
+            notes.append("ranks share a device index: %s" % [r["device_index"] for r in per_rank])
+        if checks["distinct_pci"] is not True:
+            notes.append("ranks share a PCI address: %s" % [r["pci"] for r in per_rank])
+    unbound = [i for i, r in enumerate(per_rank) if not r.get("numa_bound")]
+    checks["numa_bound"] = not unbound
+    if unbound:
+        notes.append("rank(s) %s not bound to their GPU's NUMA node (no NUMA information, or JSORB_NO_PLACEMENT)" % unbound)
+    ag = [r["all_gather_ms_mean"] for r in per_rank]
+    if gloo:
+        checks["all_gather_under_100us"] = "skipped (gloo test backend: host round trip)"
+    else:
+        checks["all_gather_under_100us"] = max(ag) < 0.1
+        if max(ag) >= 0.1:
+            notes.append("all_gather mean %.3f ms on rank %d (>= 0.1 ms: a 768-byte payload should cost link latency only - check xGMI topology / RCCL transport)" % (max(ag), ag.index(max(ag))))
+    blocks = [r["median_block_ms"] for r in per_rank]
+    fastest = min(blocks)
+    slow = [i for i, b_ in enumerate(blocks) if b_ > 1.05 * fastest]
+    checks["no_straggler_over_5pct"] = not slow
+    for i in slow:
+        r = per_rank[i]
+        why = []
+        if not r.get("numa_bound"):
+            why.append("not NUMA-bound")
+        if r["all_gather_ms_mean"] > 2 * min(ag) + 0.02:
+            why.append("slow all_gather (%.3f ms)" % r["all_gather_ms_mean"])
+        same_node = [j for j, q in enumerate(per_rank) if j != i and q.get("numa_node") == r.get("numa_node")]
+        notes.append("rank %d (device %s, pci %s, numa %s) median block %.3f ms = +%.1f %% over the fastest rank%s%s" % (
+            i, r["device_index"], r["pci"], r.get("numa_node"), blocks[i], 100.0 * (blocks[i] / fastest - 1.0),
+            (": " + ", ".join(why)) if why else ": same binding and collective time as the others - look at the GPU itself (clocks, another tenant)",
+            ("; shares NUMA node with rank(s) %s" % same_node) if same_node else ""))
+    ok = all(v is True or isinstance(v, str) for v in checks.values())
+    return {"ok": ok, "checks": checks, "diagnosis": "; ".join(notes) if notes else "all ranks within 5 % of the fastest, one device and one NUMA binding each, collective cheap"}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -148,9 +195,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the host-streamed / frame-latency / C4 side measurements")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: one lane, all handles on ONE HIP stream (clean per-kernel durations under rocprofv3)")
+    ap.add_argument("--dry-multi", action="store_true", help="N > 1 self-check only: a short run (no CPU baseline, no side measurements) whose line carries multi_gpu_diag.self_check - "
+                    "distinct devices / PCI addresses, NUMA binding, all_gather < 100 us, no rank > 5 %% slower than the fastest; exit code 3 if a check fails")
     ap.add_argument("--groups", type=int, default=1, help="split the step's pairs over this many independent left/right handle pairs on their own "
                     "HIP streams (round-1 schedule; the library now does the equivalent split internally, so the default is ONE handle pair)")
     args = ap.parse_args()
+    if args.dry_multi:
+        args.no_cpu_baseline = args.no_extras = True
+        args.min_time = min(args.min_time, 0.5)
+        args.profile_steps = 0
 
     if args.single_stream:
         os.environ["JSORB_MAX_LANES"] = "1"
@@ -411,12 +464,17 @@ def main():
         else:
             ag_ms = [a.elapsed_time(b) for a, b in ag_probe[0]]
         ag_probe[0] = None
+        props_ = torch.cuda.get_device_properties(dev)
         mine = {"median_block_ms": round(median(blocks_local) * 1e3, 3), "ms_per_step": round(median(blocks_local) / args.steps * 1e3, 4),
-                "all_gather_ms_mean": round(float(np.mean(ag_ms[2:])), 4), "all_gather_ms_max": round(float(np.max(ag_ms[2:])), 4)}
+                "all_gather_ms_mean": round(float(np.mean(ag_ms[2:])), 4), "all_gather_ms_max": round(float(np.max(ag_ms[2:])), 4),
+                "device_index": int(dev.index or 0), "pci": "%04x:%02x:%02x.0" % (props_.pci_domain_id, props_.pci_bus_id, props_.pci_device_id),
+                "numa_bound": bool(placement_info[0] and placement_info[0].get("bound")), "numa_node": (placement_info[0] or {}).get("numa_node"),
+                "pid": os.getpid()}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         multi_diag = {"per_rank": per_rank, "all_gather_clock": "wall clock around dist.all_gather (gloo)" if gloo else "events on torch's stream around dist.all_gather (RCCL)",
-                      "note": "value is made of the MAX over ranks of each block; per_rank holds every rank's own median"}
+                      "note": "value is made of the MAX over ranks of each block; per_rank holds every rank's own median",
+                      "self_check": multi_self_check(per_rank, single_device=bool(os.environ.get("JSORB_BENCH_SINGLE_DEVICE")), gloo=gloo)}
 
     # ---- BASELINE C4 shape as a side measurement: 64 pairs per iteration over all GPUs, one all_gather per iteration ----
     c4 = None
@@ -620,9 +678,13 @@ def main():
                           "other_configs_pairs_per_s": None if not other else {k_: _v(v_, "value") for k_, v_ in other.items()},
                           "other_inputs_pairs_per_s": None if not other_inputs else {k_: _v(v_, "value") for k_, v_ in other_inputs.items()}}
         print(json.dumps(out), flush=True)
+        if world > 1 and multi_diag and not multi_diag["self_check"]["ok"]:
+            print("[bench.py multi-GPU self-check] " + multi_diag["self_check"]["diagnosis"], file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if args.dry_multi and multi_diag and not multi_diag["self_check"]["ok"]:
+            sys.exit(3)
 
 
 def measure_copy_peak(torch, dev, gib=1.0, reps=6):

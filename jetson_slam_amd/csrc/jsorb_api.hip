@@ -671,19 +671,36 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         }
         // (a software pipeline across the lanes - stage s of lane j behind stage s of lane j-1 - was measured slower than free-running lanes: 77.8 k
         // against 80 k pairs/s in round 2; removed in round 6)
-#define JSORB_STAGE(id, launch_stmt) TIMED(e, id, launch_stmt)
+        // (experiments build only: JSORB_SKIP_KERNELS = bit mask of kernel ids whose launches are left out - WRONG results, what is measured is a kernel's
+        // marginal cost inside the overlapped pipeline; tools/micro/r6_exp3.sh)
+        const int skip_mask = experiment_env("JSORB_SKIP_KERNELS") ? atoi(experiment_env("JSORB_SKIP_KERNELS")) : 0;      // (read per call: the driver warms up with every kernel, then sets it)
+#define JSORB_STAGE(id, launch_stmt) do { if (!((skip_mask >> (id)) & 1)) TIMED(e, id, launch_stmt); } while (0)
         if (e->upload_pending) launch_upload_level0(e->h_upload, e->stage[0], (size_t)g.lv[0].H * g.lv[0].W, st);
         JSORB_STAGE(JSORB_K_PYRAMID, launch_pyramid(g, src, slab, e->lut_bits, m, e->pyr_lds, st));
         // single image: k_detect and k_blur (independent of each other) as ONE launch - a frame is a chain of small launches whose latencies add up
         static const bool fuse_env = !env_is(experiment_env("JSORB_FUSED_DETECT_BLUR"), 0);
         const bool fused = direct && fuse_env && !e->timing && g.blur_blocks > 0 && !g.det_compact && e->detect_lds + 12 * 1024 <= 64 * 1024;      // (k_blur's 10 KB of static LDS come on top of k_detect's request)
+        // Lane order of a batch (round 6; every arm measured A/B on one box, profiles/r06_experiments.txt).  The lanes of a batch start together and run
+        // the same stages at the same time; on handles with many keypoints per image (the yaml tiles: tile height <= 40) the ODD lanes therefore run
+        // k_blur BEFORE k_detect (the two are independent: both read the pyramid), and the even lanes' k_compact rides inside their k_blur launch
+        // (k_blur_compact, k_blur.hip; k_compact as a launch of its own is a bubble in its lane): C2 +1.3 %, C5 +1.7 %, C3 +-0 against one order for all
+        // lanes.  With large tiles (few keypoints, k_detect most of the step) the same order costs 1-2.5 %: those handles keep the plain order.
+        // Not while per-kernel timing is on (stages are timed one by one then).
+        // JSORB_LANE_ORDER (experiments build): 0 - every lane plain order with the fused launch, 1 - alternating, 2 - plain order, nothing fused.
+        const int lane_order = experiment_env("JSORB_LANE_ORDER") ? atoi(experiment_env("JSORB_LANE_ORDER")) : (g.lv[0].th <= 40 ? 1 : 2);
+        const bool blur_first = !fused && K > 1 && (j & 1) && lane_order == 1;
+        const bool fuse_bc = !fused && !direct && K > 1 && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
+        if (blur_first) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
         else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st, e->det_spill, e->det_spill_flags));
         if (e->nms_ms)
             JSORB_STAGE(JSORB_K_NMS_MS, launch_nms_ms(g, tile_out, e->ms_grid ? e->ms_grid + (size_t)f * g.lv[0].H * g.lv[0].W : nullptr,
                                                       e->ms_scratch ? e->ms_scratch + f * T : nullptr, e->p.nms_ms_mode_gpu, m, st));
-        JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_stride, m, st, e->h_counts + f * CW));
-        if (!fused) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
+        if (fuse_bc) JSORB_STAGE(JSORB_K_BLUR, launch_blur_compact(g, src, slab, blur, e->lut_bits, m, st, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_stride, e->h_counts + f * CW));
+        else {
+            JSORB_STAGE(JSORB_K_COMPACT, launch_compact(g, tile_out, kp, counts, e->row_tab + (size_t)f * g.row_tab_stride, m, st, e->h_counts + f * CW));
+            if (!fused && !blur_first) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
+        }
         JSORB_STAGE(JSORB_K_DESCRIBE, launch_describe(g, src, slab, blur, kp, counts, e->angles + f * T, e->desc + f * T * 32, e->out_kp + f * T * 6, m, st,
                                                       direct ? Deliver{e->deliver_kp_dev, e->deliver_desc_dev, e->h_kp, e->h_desc, nullptr}
                                                              : Deliver{nullptr, nullptr, nullptr, nullptr, nullptr}));
@@ -866,13 +883,14 @@ static void plan_detect(Geometry &g, bool compact_possible = true)
         g.lv[i].tree_rank_ok = (build_tree_rank(g.lv[i].tw, g.lv[i].log2_tw, tr, tr + 128) && !experiment_env("JSORB_FORCE_TREE_REPLAY")) ? 1 : 0;
     }
     // Batch handles run k_detect's compact form (score plane built late, on top of the dead image tile; positives in an LDS pool that spills into a
-    // borrowed chunk of global memory: 7 workgroups per CU instead of 4) when the tiles are small enough for bands of several tile rows - measured
-    // against the full-plane form (kernel time / pairs per second of the 4-lane pipeline): C2 tile 30 -23 % / -1 %, C3 tile 25 -23 % / +-0, C5 tile 20
-    // -22 % / +2 %, but C2 with the "1000 features" tile 58 only -8 % / -6 % (one tile row per workgroup in either form, and the full-plane request
-    // leaves a k_describe workgroup its place on every CU).  Single-image handles keep the full-plane form (one image does not fill the chip).
+    // borrowed chunk of global memory: 7 workgroups per CU instead of 4).  Round 5 kept the full-plane form for tiles above 40 rows (the "1000 / 2000 /
+    // 3000 features" tiles 58 / 46 / 52), where the compact kernel was 20-30 % faster alone and the 4-lane pipeline no faster.  Round 6 found what ate
+    // the difference - k_compact's 1024-thread workgroups starving behind the fuller CUs (k_compact.hip) - and with 256-thread compaction the compact
+    // form wins at every tile size (A/B on one box, pairs/s full-plane -> compact: tile 58 148.4 k -> 150.1 k, C3 tile 46 111.7 k -> 114.7 k, C5 tile 52
+    // 53.1 k -> 55.6 k; profiles/r06_experiments.txt).  Single-image handles keep the full-plane form (one image does not fill the chip).
     // JSORB_DETECT_FULLPLANE=1 / 0 forces the full-plane / the compact form on a batch handle (A/B measurements, tests).
     const char *force = product_env("JSORB_DETECT_FULLPLANE");
-    const bool want_compact = force ? atoi(force) == 0 : g.lv[0].th <= 40;
+    const bool want_compact = force ? atoi(force) == 0 : true;
     g.det_compact = (!g.latency && want_compact && compact_possible) ? 1 : 0;
     fill_detect_layout(g);
 }
@@ -965,6 +983,12 @@ int jsorb_create_masked(const jsorb_params *params, const uint8_t *mask, int mas
             const size_t desc = (fa.sharedSizeBytes + gran - 1) / gran * gran;
             const size_t want = desc < cu_lds ? (cu_lds - desc) / 4 / gran * gran : 0;
             if (e->detect_lds <= want) e->detect_lds = want;
+        }
+        // (experiments build: an explicit request, never below what the layout needs, never above what one workgroup may have - what else fits on a CU next
+        // to k_detect is decided by this number)
+        if (const char *rq = experiment_env("JSORB_DETECT_LDS_REQUEST")) {
+            e->detect_lds = std::max(detect_lds_bytes(g), (size_t)std::max(0, atoi(rq)));
+            if (e->detect_lds > 64 * 1024) { e->err = "JSORB_DETECT_LDS_REQUEST: a workgroup may request at most 64 KB of dynamic LDS"; return JSORB_ERR_INVALID; }
         }
     }
     e->pyr_lds = pyramid_lds_bytes(g);
@@ -1588,6 +1612,8 @@ int jsorb_stereo_match_batch_async(jsorb_extractor *l, jsorb_extractor *r, float
         ImageSrc srcL = l->src, srcR = r->src;
         srcL.l0 += (size_t)f * srcL.l0_stride;
         srcR.l0 += (size_t)f * srcR.l0_stride;
+        const int skip_mask_st = experiment_env("JSORB_SKIP_KERNELS") ? atoi(experiment_env("JSORB_SKIP_KERNELS")) : 0;
+        if (!((skip_mask_st >> JSORB_K_STEREO) & 1))
         TIMED(l, JSORB_K_STEREO, launch_stereo(l->g, srcL, l->slab + (size_t)f * l->g.slab_bytes, srcR, r->slab + (size_t)f * r->g.slab_bytes,
                                               l->out_kp + f * T * 6, l->counts + f * CW, l->desc + f * T * 32,
                                               r->out_kp + f * T * 6, r->counts + f * CW, r->desc + f * T * 32, r->row_tab + (size_t)f * r->g.row_tab_stride,

@@ -46,6 +46,9 @@ void launch_detect_blur(const Geometry &g, const ImageSrc &src, const uint8_t *s
 void fill_blur_layout(Geometry &g);        // k_blur: strips x bands per level, workgroups per level (host side, once per handle)
 int blur_level_blocks(const LevelDesc &lv);
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s);
+bool blur_compact_fusable(const Geometry &g);      // batches: k_compact as workgroup 0 of every image of the k_blur launch (k_blur.hip)
+void launch_blur_compact(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s,
+                         const unsigned long long *tile_out, unsigned long long *kp, int *counts, int *row_tab, int *counts_host);
 void launch_describe(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *blur_slab,
                      const unsigned long long *kp, const int *counts, float *angles, uint8_t *desc, int32_t *out_kp,
                      int n_images, hipStream_t s, Deliver dl = Deliver{nullptr, nullptr, nullptr, nullptr, nullptr});

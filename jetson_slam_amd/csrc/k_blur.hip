@@ -18,6 +18,7 @@
 //     a per-lane byte mask in LDS, listed per wave after the band and recomputed with the reference's 49-FMA chain, one pixel per lane.
 #include "jsorb_launch.h"
 #include "k_blur_body.h"
+#include "k_compact_body.h"
 
 namespace jsorb {
 
@@ -60,6 +61,45 @@ __global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur(Geometry 
     int b, blk;
     if (!xcd_map(g.blur_blocks, n_images, b, blk)) return;
     blur_workgroup(g, src, slab, blur_slab, ctab, b, blk);
+}
+
+// Batches: k_compact and k_blur as ONE launch (round 6).  k_compact is one workgroup per image and pure latency; as a launch of its own inside the
+// 4-lane pipeline it is a bubble in its lane (a handful of workgroups that wait for wave slots while the other lanes' kernels keep every CU full: the
+// launch took 45-70 us there, 10 us alone, and cost the step 2.5 x its stand-alone time - tools/micro/r6_skip.py).  k_blur follows it in the lane and
+// does not depend on it (it reads the pyramid, k_compact reads k_detect's tile candidates), so workgroup 0 of every image compacts (256 threads,
+// 1024 / 256 x the candidates per thread) and workgroups 1 .. blur_blocks blur: the compaction runs under k_blur's workgroups.
+// NC as in k_compact_flat: > 0 - the candidates stay in registers (images of at most 4096 tiles), 0 - re-reading form; tables for <= 32768 tiles.
+#define BLC_MAXCELLS 512
+template <int NC>
+__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_compact(Geometry g, ImageSrc src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *__restrict__ ctab, int n_images,
+                                                                               const unsigned long long *__restrict__ tile_out, unsigned long long *__restrict__ kp,
+                                                                               int *__restrict__ counts, int *__restrict__ row_tab, int *__restrict__ counts_host)
+{
+    extern __shared__ int s_epi_dyn[];
+    asm volatile("" ::"s"(ctab), "s"(slab), "s"(blur_slab), "s"(src.l0), "s"(src.l0_stride), "s"(src.l0_pitch), "s"(g.slab_bytes), "s"(g.detect_blocks));
+    int b, blk;
+    if (!xcd_map(g.blur_blocks + 1, n_images, b, blk)) return;
+    if (blk == 0) {
+        compact_flat_workgroup<NC, BLUR_THREADS, BLC_MAXCELLS>(g, tile_out, kp, counts, row_tab, counts_host, b, s_epi_dyn);
+        return;
+    }
+    blur_workgroup(g, src, slab, blur_slab, ctab, b, blk - 1);
+}
+
+bool blur_compact_fusable(const Geometry &g)
+{
+    // tables for <= 64 * BLC_MAXCELLS tiles; the bucket counters must fit next to k_blur's static LDS in what a workgroup may request
+    return g.blur_blocks > 0 && g.T <= 64 * BLC_MAXCELLS && (size_t)g.L * g.epi_rows * sizeof(int) <= 40 * 1024;
+}
+
+void launch_blur_compact(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s,
+                         const unsigned long long *tile_out, unsigned long long *kp, int *counts, int *row_tab, int *counts_host)
+{
+    const size_t epi = g.epi_rows ? (size_t)g.L * g.epi_rows * sizeof(int) : 0;
+    if (g.T <= 16 * BLUR_THREADS)
+        hipLaunchKernelGGL((k_blur_compact<16>), xcd_grid(g.blur_blocks + 1, n_images), dim3(BLUR_THREADS), epi, s, g, src, slab, blur_slab, ctab, n_images, tile_out, kp, counts, row_tab, counts_host);
+    else
+        hipLaunchKernelGGL((k_blur_compact<0>), xcd_grid(g.blur_blocks + 1, n_images), dim3(BLUR_THREADS), epi, s, g, src, slab, blur_slab, ctab, n_images, tile_out, kp, counts, row_tab, counts_host);
 }
 
 void launch_blur(const Geometry &g, const ImageSrc &src, const uint8_t *slab, uint8_t *blur_slab, const uint32_t *ctab, int n_images, hipStream_t s)

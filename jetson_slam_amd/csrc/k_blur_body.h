@@ -46,6 +46,9 @@ static_assert(BLUR_RB_TALL <= BLUR_RB_MAX && BLUR_RB_BATCH <= BLUR_RB_MAX, "band
 #define BLUR_X_LEAD 4
 #endif
 static_assert(BLUR_RB_MAX % 16 == 0 && BLUR_RB_MAX <= 32, "the per-lane row masks are read back as 16-byte units; list entries hold 5 bits of row");
+#ifndef BLUR_PREFETCH
+#define BLUR_PREFETCH 2        // input rows requested ahead of the one being evaluated
+#endif
 #define BLUR_THREADS 256
 #define BLUR_AMB_CAP 768       // listed undecided pixels per WAVE (of <= 64 * 8 * BLUR_RB_MAX = 16384) before the dense exact path takes over
 
@@ -117,16 +120,29 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
     const int NR = RB + 6;                                                          // input rows ya - 3 .. ya + RB + 2 (wave-uniform count)
     int off = (ya - 3) * pitch + x0 - 4;                                            // byte offset of the lane's 16-byte window: columns x0 - 4 .. x0 + 11
     blur_u4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    // rows 1 .. BLUR_PREFETCH - 1 are requested up front as well (NR >= 7: they always exist); ahead[0] is the row after `cur`
+    blur_u4 ahead[BLUR_PREFETCH > 1 ? BLUR_PREFETCH - 1 : 1];
+#pragma unroll
+    for (int q = 0; q + 1 < BLUR_PREFETCH; q++) { off += pitch; ahead[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }
     float Hw[7][BLUR_SW];                                                           // horizontal sums of the last 7 input rows (slot = input row mod 7)
     unsigned n_amb_lane = 0;
+    unsigned dst_row_off = (unsigned)(ya * out_pitch + x0);
 #pragma unroll 1
     for (int jb = 0; jb < NR; jb += 7) {
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int j = jb + u;
             if (j >= NR) break;                                                     // wave-uniform
-            blur_u4 nxt = cur;
-            if (j + 1 < NR) { off += pitch; nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }      // next row: in flight under this row's arithmetic
+            // BLUR_PREFETCH rows ahead of the one being evaluated are in flight: a row's arithmetic is ~170 ns, a load under a busy memory system takes
+            // longer (round 6: one row ahead 0.189 ms per step, two rows 0.178 ms, C2 +1.5 % pairs/s)
+            blur_u4 nxt = cur, far = cur;
+            if (j + BLUR_PREFETCH < NR) { off += pitch; far = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }
+            if (BLUR_PREFETCH > 1) {
+                nxt = ahead[0];
+#pragma unroll
+                for (int q = 0; q + 2 < BLUR_PREFETCH; q++) ahead[q] = ahead[q + 1];
+                ahead[BLUR_PREFETCH - 2 >= 0 ? BLUR_PREFETCH - 2 : 0] = far;
+            } else nxt = far;
             // 14 conversions: window bytes 1 .. 14 = columns x0 - 3 .. x0 + 10
             float f[14];
 #pragma unroll
@@ -181,10 +197,16 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
                 // y set (and possibly that of a byte of value 1 above one, which only sends a decided pixel through the exact code as well)
                 const unsigned y = (fr ^ (fr << 1)) & 0xFEFEFEFEu;
                 const unsigned z = (~y & (y - 0x01010101u)) & 0x80808080u;
-                ambm |= (((z >> 7) * 0x01020408u) >> 24) << (4 * wi);                  // bit 8t + 7 -> bit t: the partial products land on distinct bits, the wanted ones on 24..27
+                // bit 8t + 7 -> bit 4 wi + t: bytes of z are 0 or 128, one v_dot4_u32_u8 with the byte weights 1, 2, 4, 8 (16 .. 128 for the second dword) adds up
+                // 128 x the nibble.  (Round 6: the 32-bit multiply this replaces - (z >> 7) * 0x01020408 >> 24 - is a quarter-rate instruction, two of them per
+                // row of 8 pixels were a tenth of the kernel's issue time.)
+                ambm = __builtin_amdgcn_udot4(z, wi ? 0x80402010u : 0x08040201u, ambm, false);
             }
+            ambm >>= 7;
+            const unsigned dst_off = dst_row_off;                                    // byte offset of this output row's 8 pixels from out_base (a running sum: no 64-bit multiply per row)
+            dst_row_off += (unsigned)out_pitch;
             if (o < n_out) {
-                uint8_t *dst = out_base + (size_t)(ya + o) * out_pitch + x0;
+                uint8_t *dst = out_base + dst_off;
                 if (BLUR_X_LEAD) {
                     // whole 8-byte units, zeros outside the ROI (the row's pitch has room for the last strip: pitch >= W rounded up to 64)
                     const unsigned long long keep = ((px_mask & 1u) ? 0xFFull : 0) | ((px_mask & 2u) ? 0xFF00ull : 0) | ((px_mask & 4u) ? 0xFF0000ull : 0) | ((px_mask & 8u) ? 0xFF000000ull : 0) |

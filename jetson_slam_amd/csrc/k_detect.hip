@@ -458,6 +458,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                 const int v = c[0], vt = v + threshold, v_t = v - threshold;
                 // the 16 ring pixels as 8 packed pairs (pixel 2i in the low, 2i+1 in the high half of P[i]): every test below works
                 // on two pixels per instruction (v_pk_sub_i16 / v_perm / v_sad_u16)
+                // (ds_read_u8_d16 / _d16_hi would land the bytes in the halves of a pair register without the v_lshl_or_b32 per pair, but gfx950 runs with SRAM ECC,
+                // where a d16 load rewrites the whole register - the compiler does not use them for that reason, and neither may inline assembly)
                 unsigned P[8];
                 P[0] = (unsigned)c[3 * S] | ((unsigned)c[3 * S + 1] << 16);
                 P[1] = (unsigned)c[2 * S + 2] | ((unsigned)c[S + 3] << 16);
@@ -565,7 +567,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             // 16-bit and permute instructions, profiles/r04_valu_rate.txt).  Host-proven superset of the exact test (detect_swar6_threshold);
             // phase 2 recomputes both ring masks exactly, so a few extra survivors cost time, never a result. ----
             constexpr unsigned M6 = 0x3f3f3f3fu;
-            const unsigned cbk = (unsigned)(128 - g.det_swar_t4) * 0x01010101u;
+            unsigned cbk = (unsigned)(128 - g.det_swar_t4) * 0x01010101u;
+            asm volatile("" : "+v"(cbk));      // in a VGPR: an SGPR source operand halves the issue rate of the two instructions that use it (profiles/r04_valu_rate.txt)
             const unsigned c6 = (D0 >> 2) & M6, u6 = (Du >> 2) & M6, d6 = (Dd >> 2) & M6;
             const unsigned r6 = __builtin_amdgcn_alignbit(Dp, D0, 26) & M6;      // pixels x + 3: bytes 3 of D0 and 0..2 of Dp, each >> 2
             const unsigned l6 = __builtin_amdgcn_alignbit(D0, Dm, 10) & M6;      // pixels x - 3: bytes 1..3 of Dm and 0 of D0, each >> 2

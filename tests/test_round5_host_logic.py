@@ -39,7 +39,7 @@ def test_pyramid_lds_request_covers_the_instantiated_resampler(orb):
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_compact_detect_layout(orb, name, monkeypatch):
-    """The compact k_detect (batch handles with tiles of at most 40 rows; forced here for every configuration): at most 18 LDS granules per workgroup
+    """The compact k_detect (what every batch handle runs since round 6): at most 18 LDS granules per workgroup
     (7 workgroups per CU) unless a single tile row needs more, a pool of positives of >= 10 % of the band's region pixels, bands of whole tile rows,
     and a spill chunk that holds the largest band region (every pixel a positive) - so that no input can overflow it.  Single-image handles keep the
     full-plane form."""
@@ -47,7 +47,7 @@ def test_compact_detect_layout(orb, name, monkeypatch):
     monkeypatch.delenv("JSORB_DETECT_FULLPLANE", raising=False)
     single = orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=1)
     assert single["compact"] == 0 and single["spill_chunks"] == 0 and all(lv["det_R"] == 1 for lv in single["per_level"])      # latency layout: one tile row per workgroup
-    assert orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=64)["compact"] == (1 if tile <= 40 else 0)      # the default choice (jsorb_api.hip: plan_detect)
+    assert orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=64)["compact"] == 1      # the default choice for batch handles, whatever the tile size (jsorb_api.hip: plan_detect)
     monkeypatch.setenv("JSORB_DETECT_FULLPLANE", "0")
     p = orb.plan_launch(h, w, 1.2, L, tile, tile, max_batch=64)
     assert p["compact"] == 1

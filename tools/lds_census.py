@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from jetson_slam_amd import build as b      # noqa: E402
 
 GRAN, CU_LDS, SIMD_VGPR, MAX_WAVES_SIMD = 1280, 160 * 1024, 512, 8
-KERNELS = {"k_pyramid.hip": "9k_pyramidILb0ELb0EE", "k_detect.hip": "8k_detectILb0ELb1ELb1ELb1EE", "k_compact.hip": "14k_compact_flatILi4EE", "k_blur.hip": "6k_blurE",
+KERNELS = {"k_pyramid.hip": "9k_pyramidILb0ELb0EE", "k_detect.hip": "8k_detectILb0ELb1ELb1ELb1EE", "k_compact.hip": "14k_compact_flatILi16ELi256EE", "k_blur.hip": "6k_blurE",
            "k_describe.hip": "10k_describeE", "k_stereo.hip": "8k_stereoE"}
 MEDIAN = ("k_stereo.hip", "8k_medianILi32EE")
 
