@@ -21,7 +21,8 @@ static __constant__ unsigned c_gauss_bits[7][4] = {
     {gauss_bits(9 + 0), gauss_bits(9 + 1), gauss_bits(9 + 4), gauss_bits(9 + 9)}};
 #define c_gauss reinterpret_cast<const float (*)[4]>(c_gauss_bits)
 
-#define BLUR_SW 8              // output pixels per lane and row
+#define BLUR_SW 8              // output pixels per lane and row (round 6 measured 4 - 76 instead of 105 VGPRs, 6 instead of 4 waves per SIMD, twice the lanes:
+                               // k_blur 0.191 against 0.185 ms per step, the pipeline 2 % slower; profiles/r06_experiments.txt)
 #ifndef BLUR_RB_MAX
 #define BLUR_RB_MAX 16         // most output rows per lane; per level the host evens the bands out (fill_blur_layout).  Measured at C2 (pairs/s): 32 rows
                                // 117.2 k, 16 rows 120.0 k - six halo rows per band cost 37 % more conversions and horizontal sums, but a wave
@@ -46,6 +47,9 @@ static_assert(BLUR_RB_TALL <= BLUR_RB_MAX && BLUR_RB_BATCH <= BLUR_RB_MAX, "band
 #define BLUR_X_LEAD 4
 #endif
 static_assert(BLUR_RB_MAX % 16 == 0 && BLUR_RB_MAX <= 32, "the per-lane row masks are read back as 16-byte units; list entries hold 5 bits of row");
+#ifndef BLUR_BOUSTRO
+#define BLUR_BOUSTRO 1         // odd bands walk bottom-up (see blur_workgroup)
+#endif
 #ifndef BLUR_PREFETCH
 #define BLUR_PREFETCH 2        // input rows requested ahead of the one being evaluated
 #endif
@@ -97,11 +101,22 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
         const int band = ncs == 1 ? item : (int)__umulhi((unsigned)item, lv.blur_recip), strip = item - band * ncs;      // (2^32 / 1 does not fit the reciprocal)
         x0 = JSORB_BORDER - BLUR_X_LEAD + BLUR_SW * strip;
         ya = JSORB_BORDER + band * RB;
+        return band;
     };
     const int item = wb * BLUR_THREADS + tid;
     const bool live = item < n_items;
     int x0, ya;
-    item_geometry(live ? item : 0, x0, ya);
+    const int my_band = item_geometry(live ? item : 0, x0, ya);
+    // Walking direction of the lane: even bands top-down, odd bands BOTTOM-UP (round 6).  The six input rows around the boundary of two bands are read by
+    // both; with every band walking down, the upper band reads them at the END of its walk and the lower one at the START - a whole wave lifetime
+    // (~8 us = 36 MB of traffic at the kernel's rate, against 4 MB of L2 per XCD) apart, so they come from HBM twice: k_blur fetched 1.9 x its plane and
+    // is bound by exactly that.  Walking towards each other, the two bands reach a shared boundary at the same time.  The vertical weights are
+    // symmetric, the certificate's bound does not depend on the order of the 7-term chain, undecided pixels take the exact path either way.
+#if BLUR_BOUSTRO
+    const bool up = (my_band & 1) != 0;
+#else
+    const bool up = false;
+#endif
     const int n_out = live ? min(RB, H - JSORB_BORDER - ya) : 0;                  // output rows of this lane
     const int n_valid = min(BLUR_SW, W - JSORB_BORDER - x0);                       // the strip's pixels up to the right end of the ROI (>= 1)
     const unsigned px_mask = (n_valid >= 8 ? 0xFFu : (1u << n_valid) - 1u) & (BLUR_X_LEAD && x0 < JSORB_BORDER ? 0xFFu << (JSORB_BORDER - x0) : 0xFFu);      // pixels inside the ROI
@@ -118,15 +133,19 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
 
     // ---- fast pass: stream down the band ----
     const int NR = RB + 6;                                                          // input rows ya - 3 .. ya + RB + 2 (wave-uniform count)
-    int off = (ya - 3) * pitch + x0 - 4;                                            // byte offset of the lane's 16-byte window: columns x0 - 4 .. x0 + 11
-    blur_u4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    const int in_step = up ? -pitch : pitch;                                        // the walk's row step in the input plane ...
+    const unsigned out_step = (unsigned)(up ? -out_pitch : out_pitch);              // ... and in the output plane
+    int off = (up ? ya + RB + 2 : ya - 3) * pitch + x0 - 4;                         // byte offset of the lane's 16-byte window: columns x0 - 4 .. x0 + 11 of the walk's first input row
+    blur_u4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);             // (rows past the image - the short last band walking up - read as 0: bounds-checked buffer)
     // rows 1 .. BLUR_PREFETCH - 1 are requested up front as well (NR >= 7: they always exist); ahead[0] is the row after `cur`
     blur_u4 ahead[BLUR_PREFETCH > 1 ? BLUR_PREFETCH - 1 : 1];
 #pragma unroll
-    for (int q = 0; q + 1 < BLUR_PREFETCH; q++) { off += pitch; ahead[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }
+    for (int q = 0; q + 1 < BLUR_PREFETCH; q++) { off += in_step; ahead[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }
     float Hw[7][BLUR_SW];                                                           // horizontal sums of the last 7 input rows (slot = input row mod 7)
     unsigned n_amb_lane = 0;
-    unsigned dst_row_off = (unsigned)(ya * out_pitch + x0);
+    unsigned dst_row_off = (unsigned)((up ? ya + RB - 1 : ya) * out_pitch + x0);
+    int o_real = up ? RB - 1 : 0;                                                   // band row of the walk's next output row
+    const int o_step = up ? -1 : 1;
 #pragma unroll 1
     for (int jb = 0; jb < NR; jb += 7) {
 #pragma unroll
@@ -136,7 +155,7 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
             // BLUR_PREFETCH rows ahead of the one being evaluated are in flight: a row's arithmetic is ~170 ns, a load under a busy memory system takes
             // longer (round 6: one row ahead 0.189 ms per step, two rows 0.178 ms, C2 +1.5 % pairs/s)
             blur_u4 nxt = cur, far = cur;
-            if (j + BLUR_PREFETCH < NR) { off += pitch; far = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }
+            if (j + BLUR_PREFETCH < NR) { off += in_step; far = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); }
             if (BLUR_PREFETCH > 1) {
                 nxt = ahead[0];
 #pragma unroll
@@ -204,8 +223,10 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
             }
             ambm >>= 7;
             const unsigned dst_off = dst_row_off;                                    // byte offset of this output row's 8 pixels from out_base (a running sum: no 64-bit multiply per row)
-            dst_row_off += (unsigned)out_pitch;
-            if (o < n_out) {
+            dst_row_off += out_step;
+            const int orow = o_real;
+            o_real += o_step;
+            if (orow < n_out) {
                 uint8_t *dst = out_base + dst_off;
                 if (BLUR_X_LEAD) {
                     // whole 8-byte units, zeros outside the ROI (the row's pitch has room for the last strip: pitch >= W rounded up to 64)
@@ -219,7 +240,7 @@ __device__ __forceinline__ void blur_workgroup(const Geometry &g, const ImageSrc
                         if (k < n_valid) dst[k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 0xFFu);
                 }
                 ambm &= px_mask;
-                my_mask[o] = (unsigned char)ambm;
+                my_mask[orow] = (unsigned char)ambm;
                 n_amb_lane += __popc(ambm);
             }
         }

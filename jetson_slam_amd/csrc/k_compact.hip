@@ -97,10 +97,7 @@ void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsig
         hipLaunchKernelGGL((k_compact_flat<4, 1024>), dim3(n_images), dim3(1024), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
     else if (g.T <= 4 * 1024)
         hipLaunchKernelGGL((k_compact_flat<4 * 1024 / NB, NB>), dim3(n_images), dim3(NB), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
-#ifdef CMP_MID_512
-    else if (g.T <= 8 * 1024 && !g.latency)      // A/B arm: the KITTI-shaped images (6756 tiles) in the register form with 512 threads
-        hipLaunchKernelGGL((k_compact_flat<16, 512>), dim3(n_images), dim3(512), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
-#endif
+    // (4096 < T <= 8192 - the KITTI-shaped images - in the register form with 512 threads: measured, no difference)
     else if (g.T <= CMP_MAX_CHUNKS * 1024)
         hipLaunchKernelGGL((k_compact_flat<0, 1024>), dim3(n_images), dim3(1024), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
     else

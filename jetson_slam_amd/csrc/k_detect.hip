@@ -70,12 +70,15 @@ namespace jsorb {
 #ifndef DET_POS_PERMILLE
 #define DET_POS_PERMILLE 100
 #endif
-// LDS budget of a compact workgroup in granules of 1280 B: 18 = 7 workgroups per CU (28 waves).  Measured (C2, pairs/s of the 4-lane pipeline /
+// LDS budget of a compact workgroup in granules of 1280 B: 17 or 18 = 7 workgroups per CU (28 waves).  Round 6 (with the 256-thread k_compact and the
+// alternating lane order): 17 granules 126.1 k against 18 granules 125.1 k pairs/s at C2, three alternating runs on one box (C5: 36.7 k both) - the
+// bands are the same (the pools shrink by 320 entries), but seven workgroups now leave 11.5 KB of a CU's LDS free: room for one k_blur workgroup (10 KB)
+// of another lane next to them; 16 granules (8 workgroups per CU) 125.4 k.  Round 5 (C2, pairs/s of the 4-lane pipeline /
 // k_detect ms per step, full-plane form 121.3 k / 0.538 on that box; tools/micro/r5_exp9.sh): 17 granules with a pool of >= 18 % of the band's
 // pixels 119.0 k / 0.419, 18 / 18 % 119.4 k / 0.416, 17 / 10 % (level 1 gets a third tile row per band: 202 instead of 220 workgroups per image)
 // 118.4 k / 0.419, 18 / 10 % 120.5 k / 0.411, 19 / 10 % (6 workgroups per CU) 119.4 k / 0.440, 17 / 6 % 119.0 k / 0.415.
 #ifndef DET_CP_GRANULES
-#define DET_CP_GRANULES 18
+#define DET_CP_GRANULES 17
 #endif
 #define DET_CP_BUDGET (DET_CP_GRANULES * 1280)
 // The spill arena of a handle: 8 XCDs x DET_ARENA_SLOTS chunks.  A workgroup only ever touches the chunks of the XCD it runs on (s_getreg XCC_ID), so a
@@ -256,24 +259,6 @@ __device__ __forceinline__ unsigned ring_word_to_index(unsigned w)
 }
 int detect_ring_bit_of_pixel(int k) { return ring_bit_of_pixel(k); }
 
-// -DDET_TIMING (tools/micro/detect_phases.py builds that variant): every wave adds the shader clocks it spent in each phase to global counters
-#ifdef DET_TIMING
-#define DET_TSLOTS 2048
-__device__ unsigned long long g_det_timing[DET_TSLOTS][16];      // spread over many lines: atomics of 10^5 waves on ONE address serialise and distort what they measure
-#define DET_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define DET_TACC(k, a, b) do { det_t[k] = (b) - (a); } while (0)
-extern "C" int jsorb_debug_detect_timing(unsigned long long *out16)
-{
-    static unsigned long long h[DET_TSLOTS][16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_det_timing), sizeof(h)) != hipSuccess) return -1;
-    for (int k = 0; k < 16; k++) { out16[k] = 0; for (int i = 0; i < DET_TSLOTS; i++) out16[k] += h[i][k]; }
-    memset(h, 0, sizeof(h));
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_det_timing), h, sizeof(h)) == hipSuccess ? 0 : -1;
-}
-#else
-#define DET_T(var) do { } while (0)
-#define DET_TACC(k, a, b) do { } while (0)
-#endif
 
 // one workgroup of k_detect: image b, workgroup blk of the image's g.detect_blocks (a kernel of its own for batches, one half of the fused
 // k_detect_blur launch for single frames - both below)
@@ -319,10 +304,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i32(tid >> 6);      // (tid >> 6 is wave-uniform, but only a readfirstlane proves it to the compiler: loop counters and list sizes derived from it then live in SGPRs)
-#ifdef DET_TIMING
-    unsigned long long det_t[10] = {};
-#endif
-    DET_T(t_start);
     // workgroup descriptor (level, tile row, tile group) from the host-built table behind the LUT: one scalar load instead of a
     // chain of dependent ones - the kernel is sensitive to the latency of this prologue (no vector work can start before it)
     const unsigned wd = ctab_load(lut_bits, CTAB_DETECT + blk);
@@ -385,10 +366,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         if (tid < 128) s_colkey[tid] = 0;
         if (lv.tree_rank_ok && tid < 64) reinterpret_cast<unsigned *>(s_tree)[tid] = lut_bits[ctab_tree(g) + 64 * lvl + tid];      // column priorities
     }
-    DET_T(t_staged);
     __syncthreads();
-    DET_T(t_p1);
-    DET_TACC(0, 0ull, 1ull); DET_TACC(1, t_start, t_staged); DET_TACC(2, t_staged, t_p1);
 
     // ---- phase 1: the two early rejects on every pixel of the (th+2) x (ktw+2) score region, 4 pixels per lane ----
     // LDS column c <-> image x = xs + c ; region column rx <-> c = c0 + rx.  A lane owns one aligned LDS dword (4 pixels)
@@ -437,14 +415,10 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     // each wave on ITS OWN survivor list (no barrier after phase 1) ----
     // Survivors whose arc test succeeds are compacted in place (ballot + popcount) to the front of the same list: writes of a
     // step land at or below the indices the step has just read, and LDS operations of one wave execute in order.
-#ifdef DET_TIMING
-    unsigned long long t_ring = 0;
-#endif
     // Compact form: the pending survivors are the whole list [0, n_mine); a pass takes full chunks of 64 from its END (the order of the entries is
     // free) and leaves the < 64 others pending unless it is the wave's last pass, so every ring test but the last one runs on a full wave; a positive goes
     // to the workgroup's pool of positives (or its spill chunk) with its score.
     auto ring_pass = [&](bool last) {
-        DET_T(t_r0);
         (void)last;
         for (int i0 = CP ? n_mine - 64 : n_pos; CP ? (n_mine > 0 && (last || i0 >= 0)) : i0 < n_mine; i0 += CP ? -64 : 64) {
             const int i = i0 + lane;
@@ -533,9 +507,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             if (dense || n_pos > flush_at) { dense = true; n_pos = 0; }          // not even the positives fit: dense scan in phase 3
             n_mine = n_pos;
         }
-#ifdef DET_TIMING
-        t_ring += __builtin_amdgcn_s_memtime() - t_r0;
-#endif
     };
     // The wave's early-reject steps: rows rbase (+1) of the region, every 4th step of the workgroup.  Steps whose rows all lie in the
     // image's 20-pixel border have no pixel to test (12 % of the steps at the EuRoC geometry, 30 % of the rows of the smallest level):
@@ -657,13 +628,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     DET_RING_PASS(true);
 #undef DET_RING_PASS
 #undef PK
-    DET_T(t_p2);
-#ifdef DET_TIMING
-    DET_TACC(3, t_p1 + t_ring, t_p2); DET_TACC(4, 0ull, t_ring);
-#endif
     __syncthreads();
-    DET_T(t_p3);
-    DET_TACC(5, t_p2, t_p3);
     int n_all = 0;                                        // compact form: positives of the band (pool + spill chunk)
     const unsigned *spill_chunk = nullptr;
     if constexpr (CP) {
@@ -693,8 +658,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         }
         __syncthreads();
     }
-    DET_T(t_plane);
-    DET_TACC(9, t_p3, t_plane);                           // compact form: zero + barrier + scatter + barrier
 
     // ---- phase 3: 3x3 NMS (>= on the 8 neighbours) + arg-max key, positives of the wave's own list ----
     // (list entries always have a positive score; the `s > 0` test only matters for the dense fallback)
@@ -752,7 +715,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             for (int ry = rbase; ry < rbase + rows_per_step && ry < L.score_rows; ry++)
                 for (int rx = lane; rx < L.score_w; rx += 64) nms_one(ry, rx, 0);
     }
-    DET_T(t_p3e);
     __syncthreads();
     if constexpr (CP) {
         // every thread has read its spilled entries (the barrier waits for outstanding loads): the chunk goes back to the arena
@@ -760,8 +722,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         // release would write the whole L2 back)
         if (tid == 0 && spill_chunk) __hip_atomic_store(spill_flags + (s_overflow[2] - 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    DET_T(t_p4);
-    DET_TACC(6, t_plane, t_p3e); DET_TACC(7, t_p3e, t_p4);
 
     if (ranked) {
         // ---- phase 4 (arg-max form): one thread per tile decodes the winner ----
@@ -782,14 +742,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             tile_out[(size_t)b * g.T + lv.tile_off + tile_idx] =
                 ((unsigned long long)(unsigned)sc << 32) | ((unsigned)(yy & 0xFFFF) << 16) | (unsigned)(xx & 0xFFFF);
         }
-        DET_T(t_end);
-        DET_TACC(8, t_p4, t_end);
-#ifdef DET_TIMING
-        if (lane == 0) {
-            unsigned long long *slot = g_det_timing[(blockIdx.x + 8 * blockIdx.y + 977 * blockIdx.z + 131 * wave) & (DET_TSLOTS - 1)];
-            for (int k = 0; k < 10; k++) atomicAdd(slot + k, det_t[k]);
-        }
-#endif
         return;
     }
 

@@ -54,7 +54,10 @@ __device__ __forceinline__ void wave_lds_sync_st()
 //  C   lane = keypoint again: arg-min of the 11 sums, parabola, disparity test, depth, and one coalesced store per output array.
 #define ST_MAX_PASS 8
 #define ST_MAX_KP (SKPW * ST_MAX_PASS)
-__global__ __launch_bounds__(64) void k_stereo(Geometry g, ImageSrc srcL, const uint8_t *slabL, ImageSrc srcR, const uint8_t *slabR,
+#ifndef ST_MIN_WAVES
+#define ST_MIN_WAVES 5         // waves per SIMD the register allocation must allow (88 VGPRs as compiled: 5)
+#endif
+__global__ __launch_bounds__(64, ST_MIN_WAVES) void k_stereo(Geometry g, ImageSrc srcL, const uint8_t *slabL, ImageSrc srcR, const uint8_t *slabR,
                                                const int32_t *__restrict__ outL, const int *__restrict__ countsL, const uint8_t *__restrict__ descL,
                                                const int32_t *__restrict__ outR, const int *__restrict__ countsR, const uint8_t *__restrict__ descR,
                                                const int *__restrict__ row_tabR,
