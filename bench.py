@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: one lane, all handles on ONE HIP stream (clean per-kernel durations under rocprofv3)")
     ap.add_argument("--dry-multi", action="store_true", help="N > 1 self-check only: a short run (no CPU baseline, no side measurements) whose line carries multi_gpu_diag.self_check - "
-                    "distinct devices / PCI addresses, NUMA binding, all_gather < 100 us, no rank > 5 %% slower than the fastest; exit code 3 if a check fails")
+                    "distinct devices / PCI addresses, NUMA binding, all_gather < 100 us, no rank > 5 %% slower than the fastest; the ranks exit with 3 if a check fails (a launcher reports that as a failed worker)")
     ap.add_argument("--groups", type=int, default=1, help="split the step's pairs over this many independent left/right handle pairs on their own "
                     "HIP streams (round-1 schedule; the library now does the equivalent split internally, so the default is ONE handle pair)")
     args = ap.parse_args()
@@ -573,6 +573,17 @@ def main():
                 "pipeline_achieved": round(ab * pairs_per_s / world / 1e9, 1),
                 "pipeline_frac": round(ab * pairs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step_ms.items()}}
+        # SURVEY 8(d) left the data-dependent bytes out of ALGO_BYTES as "< 6 %": outputs 56 N per image and, for the matcher, 64 N + 12 C + 462 M (N left
+        # keypoints, C candidate pairs, M window searches).  On the benchmark images they are a THIRD of the figure (round-5 review) - reported here as a
+        # second figure from the counts of the step's first pair; `frac` keeps the input-independent convention.
+        try:
+            _u0, _d0, st0 = orb.stereo_result(exl, 0)
+            nl0, nr0 = exl.n_keypoints(0), exr.n_keypoints(0)
+            extra = 56 * (nl0 + nr0) + 64 * nl0 + 12 * int(st0["n_candidate_pairs"]) + 462 * int(st0["n_corr_match"])
+            roof["algo_bytes_per_pair_incl_outputs_and_stereo"] = int(ab + extra)
+            roof["data_dependent_share"] = round(extra / float(ab + extra), 3)
+        except Exception:
+            pass
         if traffic:
             roof["kernel_own_hbm_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)      # the dominant kernel's own PMC bytes / its duration / peak
         if step_traffic:

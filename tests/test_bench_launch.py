@@ -44,6 +44,18 @@ def test_bench_launches_two_ranks_itself_and_gathers_counts():
     assert len(diag["per_rank"]) == 2 and all(r_["median_block_ms"] > 0 and r_["ms_per_step"] > 0 and r_["all_gather_ms_mean"] >= 0 and r_["all_gather_ms_max"] >= r_["all_gather_ms_mean"]
                                               for r_ in diag["per_rank"])
     assert max(r_["ms_per_step"] for r_ in diag["per_rank"]) <= d["ms_per_step"] * 1.5 and d["summary"]["pairs_per_s"] == d["value"]
+    # round 6: the record checks itself (device / PCI / collective checks are "skipped" under the single-device gloo hook, never "failed")
+    sc = diag["self_check"]
+    assert set(sc["checks"]) == {"distinct_devices", "distinct_pci", "numa_bound", "all_gather_under_100us", "no_straggler_over_5pct"} and isinstance(sc["diagnosis"], str)
+    assert isinstance(sc["checks"]["distinct_devices"], str) and isinstance(sc["checks"]["all_gather_under_100us"], str)
+    assert all("pci" in r_ and "device_index" in r_ and "numa_bound" in r_ for r_ in diag["per_rank"])
+    # --dry-multi: the self-check alone, in seconds; the exit code is non-zero iff a check failed (e.g. the two ranks of this box drift more than 5 % apart;
+    # a rank exits with 3, which the launcher reports as a failed worker)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-multi", "--steps", "3", "--warmup", "1", "--pairs", "6", "--config", "c1"],
+                       env=_clean_env(JSORB_BENCH_SINGLE_DEVICE="1", JSORB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    dd = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert dd["multi_gpu_diag"]["self_check"]["ok"] == (r.returncode == 0), r.stderr[-2000:]
+    assert dd["cpu_baseline"] is None
     # strong scaling shape (BASELINE C4 style): the total is split over the ranks
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--pairs-total", "8"],
                        env=_clean_env(JSORB_BENCH_SINGLE_DEVICE="1", JSORB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600, cwd=ROOT)
