@@ -432,6 +432,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                 const int v = c[0], vt = v + threshold, v_t = v - threshold;
                 // the 16 ring pixels as 8 packed pairs (pixel 2i in the low, 2i+1 in the high half of P[i]): every test below works
                 // on two pixels per instruction (v_pk_sub_i16 / v_perm / v_sad_u16)
+                // (Round 6 measured the chain list entry -> address -> 17 byte reads requested ONE CHUNK AHEAD, raw bytes kept in 17 registers across the
+                // iteration: k_detect 0.41 -> 0.45 ms per step, the pipeline -1.6 % - dropped, profiles/r06_experiments.txt.)
                 // (ds_read_u8_d16 / _d16_hi would land the bytes in the halves of a pair register without the v_lshl_or_b32 per pair, but gfx950 runs with SRAM ECC,
                 // where a d16 load rewrites the whole register - the compiler does not use them for that reason, and neither may inline assembly)
                 unsigned P[8];
@@ -462,8 +464,16 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                 // with fewer set bits than any accepted mask skip it (bright and dark are disjoint: with N_MIN >= 9 at most one
                 // of them is ever looked up, usually none)
                 unsigned lb = 0;
-                if (__popc(bright) >= min_pop) { const unsigned ix = ring_word_to_index(bright); lb = lut_bits[ix >> 5] >> (ix & 31); }
-                if (__popc(dark) >= min_pop) { const unsigned ix = ring_word_to_index(dark); lb |= lut_bits[ix >> 5] >> (ix & 31); }
+                if (min_pop >= 9) {
+                    // bright and dark are disjoint subsets of 16 ring pixels: with N_MIN >= 9 at most ONE of them can reach min_pop, so one lookup per
+                    // pixel decides - one load and one memory round trip per chunk of 64 ring tests, where two conditional lookups were two dependent
+                    // round trips in the middle of the pass whenever a chunk held candidates of both polarities (round 6)
+                    const unsigned m = __popc(bright) >= min_pop ? bright : dark;
+                    if (__popc(m) >= min_pop) { const unsigned ix = ring_word_to_index(m); lb = lut_bits[ix >> 5] >> (ix & 31); }
+                } else {
+                    if (__popc(bright) >= min_pop) { const unsigned ix = ring_word_to_index(bright); lb = lut_bits[ix >> 5] >> (ix & 31); }
+                    if (__popc(dark) >= min_pop) { const unsigned ix = ring_word_to_index(dark); lb |= lut_bits[ix >> 5] >> (ix & 31); }
+                }
                 hit = (lb & 1u) != 0;
                 if (hit) {
                     const unsigned v2 = (unsigned)v * 0x10001u;
