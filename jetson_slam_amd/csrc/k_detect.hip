@@ -348,7 +348,24 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         const uint8_t *p16 = img + (ptrdiff_t)(y0 - 4 + ly0) * pitch + x;
         uint4 *dst = reinterpret_cast<uint4 *>(s_img) + tid;
         int y = y0 - 4 + ly0;
-        for (int ly = ly0; ly < L.img_rows; ly += rpp) {
+        // ALL of a thread's rows are requested before the first one is stored (round 6): written as one loop - load, store, next row - the compiler waits
+        // for every load before the next is issued, three to five dependent memory round trips in front of the workgroup's first barrier.  A band has at
+        // most DET_STAGE_MAX * 25 rows (tiles of up to 128 rows + 8: 6 passes); taller ones take the rest in the plain loop.
+        constexpr int DET_STAGE_MAX = 6;
+        uint4 sv[DET_STAGE_MAX];
+#pragma unroll
+        for (int k = 0; k < DET_STAGE_MAX; k++) {
+            sv[k] = make_uint4(0, 0, 0, 0);
+            const int yk = y + k * rpp;
+            if (ly0 + k * rpp < L.img_rows && x_ok && yk >= 0 && yk < H) sv[k] = *reinterpret_cast<const uint4 *>(p16 + (size_t)k * rpp * pitch);
+        }
+#pragma unroll
+        for (int k = 0; k < DET_STAGE_MAX; k++)
+            if (ly0 + k * rpp < L.img_rows && tid < rpp * nq16) dst[k * rpp * nq16] = sv[k];
+        p16 += (size_t)DET_STAGE_MAX * rpp * pitch;
+        dst += DET_STAGE_MAX * rpp * nq16;
+        y += DET_STAGE_MAX * rpp;
+        for (int ly = ly0 + DET_STAGE_MAX * rpp; ly < L.img_rows; ly += rpp) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (x_ok && y >= 0 && y < H) v = *reinterpret_cast<const uint4 *>(p16);
             if (tid < rpp * nq16) *dst = v;
