@@ -594,6 +594,16 @@ def main():
         vv = valu_view(args.config if args.tile <= 0 else "", pairs_per_s / world, props.multi_processor_count, props.clock_rate * 1e3 if getattr(props, "clock_rate", 0) else 2.4e9)
         if vv:
             roof.update(vv)
+            # the two clocks side by side (round-5 review): `avg_launch_ms` above is this run's hipEvent time of the dominant kernel on its own stream (the
+            # --profile-steps pass), this one the builder's rocprofv3 --kernel-trace average of the same launch shape (profiles/valu_counters.json, digest-checked)
+            try:
+                tj_ = json.load(open(os.path.join(ROOT, "profiles", "valu_counters.json")))
+                us_ = tj_[args.config]["avg_us"].get("k_compact_flat" if dom == "k_compact" else dom) if args.tile <= 0 and per == int(tj_[args.config]["_pairs_per_launch"]) else None
+                if us_:
+                    roof["avg_launch_ms_rocprofv3"] = round(us_ / 1e3, 4)
+                    roof["frac_with_rocprofv3_duration"] = round(ab * units / (us_ * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            except Exception:
+                pass
         if not args.no_extras:
             pm = measure_copy_peak(torch, dev)
             roof["peak_measured"] = pm
