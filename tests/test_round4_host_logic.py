@@ -26,16 +26,23 @@ def _define(src, name):
     return int(m.group(1))
 
 
-def _describe_rows(bq, shifted):
+def _define_row40(src, name):
+    return _define(src, name)
+
+
+def _describe_rows(bq, layout):
     """rows of the un-blurred patch a quad stages in steps 0..7 (k_describe.hip: row0, row6, row7)"""
-    if not shifted:                                   # round 3: rows q + 4k, last step min(28 + q, 30)
+    if layout == "round3":                            # rows q + 4k, last step min(28 + q, 30)
         return [bq + 4 * k for k in range(7)] + [min(28 + bq, 30)]
-    row0 = bq + (4 if bq >= 2 else 0)
-    return [row0 + 4 * k for k in range(6)] + [min(row0 + 24, 30), bq if bq >= 2 else 28 + bq]
+    if layout == "round4":                            # quads 2 and 3 one step ahead (56-byte rows)
+        row0 = bq + (4 if bq >= 2 else 0)
+        return [row0 + 4 * k for k in range(6)] + [min(row0 + 24, 30), bq if bq >= 2 else 28 + bq]
+    return [bq + 4 * k for k in range(8)]             # round 6, 40-byte rows: rows 4k + q, step 7 = rows 28 .. 31
 
 
-def _store_cycles(shifted, stride, patch_bytes):
-    """LDS cycles of the 16 ds_write_b64 halves of one wave (4 keypoints x 4 quads x 3 storing lanes), one cycle per group when conflict-free"""
+def _store_cycles(layout, stride, patch_bytes):
+    """LDS cycles of the ds_write_b64 halves of one wave (4 keypoints x 4 quads x 3 storing lanes), one cycle per group when conflict-free; with 40-byte
+    rows the third unit stores only its first half"""
     total = 0
     for k in range(8):
         for half in range(2):
@@ -43,9 +50,9 @@ def _store_cycles(shifted, stride, patch_bytes):
                 banks = {}
                 for sl in range(16):
                     bq, bu = sl >> 2, sl & 3
-                    if bu == 3:
+                    if bu == 3 or (layout == "round6" and bu == 2 and half == 1):
                         continue                      # the fourth lane of a quad repeats unit 2 and stores nothing
-                    a = grp * patch_bytes + _describe_rows(bq, shifted)[k] * stride + 16 * bu + 8 * half
+                    a = grp * patch_bytes + _describe_rows(bq, layout)[k] * stride + 16 * bu + 8 * half
                     for dw in (a // 4, a // 4 + 1):
                         banks.setdefault(dw % 32, set()).add(dw)
                 total += max(len(v) for v in banks.values())
@@ -54,19 +61,26 @@ def _store_cycles(shifted, stride, patch_bytes):
 
 def test_describe_patch_staging_covers_every_row_and_its_stores_do_not_share_banks():
     src = _src("k_describe.hip")
-    stride = _define(src, "ORI_LDS_STRIDE")
-    patch_bytes = 37 * _define(src, "BLR_Q") * 8
-    assert "const int row0 = bq + (bq >= 2 ? 4 : 0);" in src and "row6 = min(row0 + 24, 30), row7 = bq >= 2 ? bq : 28 + bq" in src
-    rows = sorted(r for bq in range(4) for r in _describe_rows(bq, True))
-    assert set(rows) == set(range(31)) and rows.count(30) == 2 and len(rows) == 32          # row 30 twice (same bytes), nothing beyond the region
-    assert max(rows) * stride + 48 <= patch_bytes
-    # the assignment in the tree is conflict-free except for the step in which two quads write the same row 30
-    new, old = _store_cycles(True, stride, patch_bytes), _store_cycles(False, stride, patch_bytes)
-    assert old >= 2 * 14 * 4 and new <= 16 * 4 + 2 * 4, (old, new)
-    # steps 0..5 walk with a constant stride from row0 (the kernel's pointer increments)
-    for bq in range(4):
-        r = _describe_rows(bq, True)
-        assert all(r[k + 1] - r[k] == 4 for k in range(5))
+    stride = _define_row40(src, "ORI_LDS_STRIDE")
+    patch_bytes = 37 * _define_row40(src, "BLR_Q") * 8
+    assert stride == 40 and patch_bytes == 1480
+    assert "const int row0 = bq;" in src and "const int row6 = row0 + 24, row7 = row0 + 28;" in src
+    rows = sorted(r for bq in range(4) for r in _describe_rows(bq, "round6"))
+    assert rows == list(range(32))                                          # rows 0 .. 30 are the disc, row 31 is staged too and lies inside the region
+    assert max(rows) * stride + 40 <= patch_bytes
+    # a window of 40 bytes from the 4-byte aligned column below the first pixel holds the 31 resp. 37 pixels of a patch row
+    assert 3 + 31 <= 40 and 3 + 37 <= 40
+    # 10-dword rows: the four consecutive rows of a store group never share a bank (no staggering needed); the 48 / 56-byte layouts of rounds 3 / 4 for comparison
+    new = _store_cycles("round6", stride, patch_bytes)
+    assert new == 8 * 2 * 4, new                                           # one cycle per 16-lane group: conflict-free
+    assert _store_cycles("round3", 56, 1776) >= 2 * 14 * 4 and _store_cycles("round4", 56, 1776) <= 16 * 4 + 2 * 4
+    # the 16 rows y - 15 + v .. a keypoint's lanes read at once for the moments start in 16 different banks
+    assert len({(r * stride // 4) % 32 for r in range(16)}) == 16
+    # workgroups per CU: 16 keypoints x 1480 B + pattern + level table + moment table = 25 984 B = 21 granules -> SIX per CU (five with 1776-byte regions)
+    kpwg = _define(src, "KPW") * _define(src, "WPW")
+    static_lds = kpwg * patch_bytes + 256 * 4 + 16 * 16 + 8 * 16 * 2 * 4
+    assert static_lds == 25984 and (160 * 1024) // (-(-static_lds // 1280) * 1280) == 6
+    assert _define(src, "DESC_MIN_WAVES") == 6                              # ... and the register allocation must allow the six waves per SIMD
 
 
 def test_stereo_flat_task_list_index_arithmetic():
@@ -109,10 +123,10 @@ def test_detect_lds_request_leaves_one_describe_workgroup_per_cu():
     assert "(cu_lds - desc) / 4 / gran * gran" in src and "gran = 1280" in src
     d = _src("k_describe.hip")
     kpwg = _define(d, "KPW") * _define(d, "WPW")
-    static_lds = kpwg * 37 * _define(d, "BLR_Q") * 8 + 256 * 4 + 16 * 16 + 8 * 16 * 2 * 4      # patches, pattern, level table (JSORB_MAX_LEVELS int4), moment table
+    static_lds = kpwg * 37 * _define_row40(d, "BLR_Q") * 8 + 256 * 4 + 16 * 16 + 8 * 16 * 2 * 4      # patches, pattern, level table (JSORB_MAX_LEVELS int4), moment table
     gran, cu = 1280, 160 * 1024
     desc = (static_lds + gran - 1) // gran * gran
     want = (cu - desc) // 4 // gran * gran
-    assert static_lds == 30720 and want == 33280
+    assert static_lds == 25984 and want == 33280
     assert 4 * want + desc <= cu < 4 * (want + gran) + desc                 # four k_detect workgroups + one k_describe workgroup fit, a granule more does not
     assert 5 * want > cu                                                   # and a fifth k_detect workgroup does not fit
