@@ -25,7 +25,7 @@ JSORB_HD constexpr int umax15(int v)
 
 // Pattern as FP8 (OCP E4M3: the integers up to 16 are exact, the pattern's coordinates lie in [-13, 13]): one dword per descriptor
 // bit = (x0, x1, y0, y1), which two v_cvt_pk_f32_fp8 expand into the register pairs the packed-f32 instructions take.  1 KB of LDS
-// instead of 4 KB of floats (5 workgroups per CU instead of 4: the kernel waits on dependent latencies, so resident waves are what it
+// instead of 4 KB of floats (one more workgroup per CU: the kernel waits on dependent latencies, so resident waves are what it
 // needs) and 4 x 16-byte LDS reads per lane instead of 16.  The 16 dwords of lane sl (steps it = 0..15: descriptor bit it*16 + sl)
 // are contiguous; their four 16-byte chunks are rotated by sl >> 2 so that the 16 lanes of a keypoint hit 16 different bank groups.
 #ifndef DESC_FP8_BIAS
@@ -51,8 +51,8 @@ JSORB_HD constexpr PatternQ make_pattern_q()
                                             fp8_e4m3_of_int(Y[2 * b + 1]) << 24;
     return t;
 }
-// Intensity centroid (K8).  The un-blurred patch is staged as 31 rows of 48 B (56-byte row stride in LDS) from the 8-byte aligned
-// column xa = (x - 15) & ~7.  Lane v (0..15) of a keypoint owns the two rows y + v and y - v, which have the same extent umax[v]:
+// Intensity centroid (K8).  The un-blurred patch is staged as 31 rows of 40 B (round 6; rounds 3-5: 48 B at a 56-byte stride) from the 4-byte aligned
+// column xa = (x - 15) & ~3.  Lane v (0..15) of a keypoint owns the two rows y + v and y - v, which have the same extent umax[v]:
 // in step d (0..7) it takes from each of them the dword of columns u = -15 + 4d .. -12 + 4d (two aligned LDS dwords and a
 // v_alignbyte by (x - 15) & 3) and feeds it to v_dot4_u32_u8 with the multipliers of this table: .x = |u| of the four bytes (0
 // outside the disc), .y = 1 for a byte inside the disc.  Steps 0..3 hold u <= 0, steps 4..7 u > 0, so the sign of u is a property of

@@ -92,3 +92,20 @@ def test_every_getenv_of_the_product_goes_through_jsorb_env_h():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in product:
         assert name in doc, name
+
+
+def test_source_digest_ignores_comments_and_sees_code():
+    """profiles/valu_counters.json / valu_mix.json are stamped with a digest of the kernel sources' CODE: editing a comment must not drop the
+    profile-derived view from the bench line, editing an instruction must (jetson_slam_amd/build.py:_code_only)."""
+    from jetson_slam_amd import build as b
+    src = 'int f(int a) {   // adds one\n    /* block\n comment */ return a + 1;      // "quoted" comment\n\n    const char *s = "// not a comment";\n}\n'
+    same = 'int f(int a) {\n    return a + 1;   // another text\n    const char *s = "// not a comment";   /* x */\n}\n'
+    other = src.replace("a + 1", "a + 2")
+    assert b._code_only(src) == b._code_only(same)
+    assert b._code_only(src) != b._code_only(other)
+    assert '"// not a comment"' in b._code_only(src) and "adds one" not in b._code_only(src)
+    # the committed profile files belong to the committed kernels
+    import json
+    sha = b.csrc_sha256()
+    for name in ("valu_counters.json", "valu_mix.json"):
+        assert json.load(open(os.path.join(ROOT, "profiles", name)))["_csrc_sha256"] == sha, name + " was measured on other kernel sources"
