@@ -703,7 +703,8 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         const unsigned short *q = s_score + __umul24(ry, SW) + rx;     // (24-bit multiplies: v_mul_lo_u32 issues at a quarter of the rate)
         const int s = CP ? s_known : q[0];
         const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
-                           s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];      // (all nine reads at once + one maximum + one branch: measured 0.9 % slower, rounds 3 and 4)
+                           s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];      // (all nine reads at once + one maximum + one branch: measured 0.9 % slower, rounds 3 and 4;
+                                                                             //  round 6, compact form, eight reads + packed maxima: k_detect +3 %, C2 -1.4 % - most lanes leave after a compare or two)
         if (!valid) return;
         int dy = ry - 1, trow = 0;                                       // tile row inside the band and row inside that tile (R <= 4)
         if (R > 1) {
