@@ -702,10 +702,28 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         if (ry < 1 || ry > th || rx < 1 || rx > ktw) return;          // halo entries only serve as neighbours
         const unsigned short *q = s_score + __umul24(ry, SW) + rx;     // (24-bit multiplies: v_mul_lo_u32 issues at a quarter of the rate)
         const int s = CP ? s_known : q[0];
-        const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
-                           s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];      // (all nine reads at once + one maximum + one branch: measured 0.9 % slower, rounds 3 and 4;
-                                                                             //  round 6, compact form, eight reads + packed maxima: k_detect +3 %, C2 -1.4 % - most lanes leave after a compare or two)
-        if (!valid) return;
+        if constexpr (CP) {
+            // Compact form (the score travels with the entry, the plane is read-only here): the eight neighbours are requested TOGETHER and compared with one
+            // maximum - one LDS round trip per positive where the short-circuit chain below is up to eight dependent ones (k_detect -3 %, C2 +0.7 %, tile 58
+            // +1.3 %, round 6).  As inline assembly on purpose: written in C++ the compiler merges neighbouring u16 reads into ds_read_b32 at 2-byte aligned
+            // addresses, and LDS reads that are not naturally aligned are slow on this part - that form was 3 % SLOWER than the chain, and the ring test's
+            // 17 byte reads as 7 unaligned wide ones doubled the kernel's time (profiles/r06_experiments.txt, sections 23-25).
+            const unsigned a_mid = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)(q - 1);
+            const unsigned a_up = a_mid - 2u * (unsigned)SW, a_dn = a_mid + 2u * (unsigned)SW;
+            unsigned n0, n1, n2, n3, n4, n5, n6, n7;
+            asm volatile("ds_read_u16 %0, %8\n\tds_read_u16 %1, %8 offset:2\n\tds_read_u16 %2, %8 offset:4\n\t"
+                         "ds_read_u16 %3, %9\n\tds_read_u16 %4, %9 offset:4\n\t"
+                         "ds_read_u16 %5, %10\n\tds_read_u16 %6, %10 offset:2\n\tds_read_u16 %7, %10 offset:4\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(n4), "=&v"(n5), "=&v"(n6), "=&v"(n7)
+                         : "v"(a_up), "v"(a_mid), "v"(a_dn) : "memory");
+            const unsigned m = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+            if ((unsigned)s < m) return;
+        } else {
+            const bool valid = s > 0 && s >= q[-SW - 1] && s >= q[-SW] && s >= q[-SW + 1] && s >= q[-1] && s >= q[1] &&
+                               s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];      // (full-plane form: all nine reads at once + one maximum + one branch measured 0.9 % slower, rounds 3 and 4)
+            if (!valid) return;
+        }
         int dy = ry - 1, trow = 0;                                       // tile row inside the band and row inside that tile (R <= 4)
         if (R > 1) {
             trow = (dy >= th1) + (dy >= 2 * th1) + (dy >= 3 * th1);
