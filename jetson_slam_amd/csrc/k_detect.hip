@@ -660,8 +660,6 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     const unsigned *spill_chunk = nullptr;
     if constexpr (CP) {
         // ---- compact form: the score plane is built now, where the image tile and the survivor lists were (every wave is past them) ----
-        n_all = (int)s_overflow[1];
-        if (n_all > pos_cap) spill_chunk = spill + (size_t)(s_overflow[2] - 1u) * (unsigned)chunk_entries;
         // The whole workgroup zeroes the plane with 16-byte stores, a barrier, then thread i scatters entries i, i + 256, ... (pool, then spill chunk).
         // (A form with one barrier less - every wave zeroes the rows it owned in phase 1 and scatters the entries of those rows - was slower: ~30 dword
         // stores per lane instead of 4 wide ones, and every wave reads the whole pool: 110.5 k against 112.5 k pairs/s.)
@@ -670,6 +668,9 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
             const int n16 = (sstr * ((L.score_rows + 1) & ~1) * 2 + 15) >> 4;
             uint4 *z = reinterpret_cast<uint4 *>(s_score);
             for (int i = tid; i < n16; i += DET_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+            // (the band's count is read behind the zeroing stores, which do not depend on it: in front of them it was a round trip with the whole workgroup waiting)
+            n_all = (int)s_overflow[1];
+            if (n_all > pos_cap) spill_chunk = spill + (size_t)(s_overflow[2] - 1u) * (unsigned)chunk_entries;
             __syncthreads();
             // (two loops, not one with a select between the pool and the chunk: a pointer that may be either makes every load a flat_load)
             const int n_lds = min(n_all, pos_cap);
