@@ -250,6 +250,7 @@ int build_geometry(const jsorb_params &p, Geometry &g, std::string &err)
         lv.mini_tile = (lv.th - 1) / n_ty + 1;
         lv.recip_nty = (65536 + n_ty - 1) / n_ty;
         lv.recip_tw = (65536 + lv.tw - 1) / lv.tw;
+        lv.recip_th = (65536 + lv.th - 1) / lv.th;
         lv.log2_tw = 0;
         while ((1 << lv.log2_tw) < lv.tw) lv.log2_tw++;
         // this build's workgroup tables

@@ -167,7 +167,9 @@ __host__ __device__ inline int detect_flush_at(const DetectLds &d)
 // fixed); the levels above it have smaller tiles and their workgroups would leave most of that allocation unused while paying the
 // same fixed cost (scalar prologue, staging passes, barriers, list bookkeeping - about 150 VALU + 500 SALU per wave, a third of a
 // wave's instructions at 8-row tiles).  Those levels put as many tile rows into one workgroup as fit into the SAME allocation.
-#define DET_MAX_R 4
+#ifndef DET_MAX_R
+#define DET_MAX_R 8
+#endif
 void fill_detect_layout(Geometry &g)
 {
     const int cp = g.det_compact;
@@ -340,7 +342,9 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
         const int ry_lo_e = max(0, JSORB_BORDER - (y0 - 1)), ry_hi_e = min(L.score_rows - 1, H - JSORB_BORDER - 1 - (y0 - 1));
         if (lv.tree_rank_ok && (c_hi_e <= c_lo_e || ry_hi_e < ry_lo_e)) {
             const int kt = lv.k_tiles;
-            const int trow = (tid >= kt) + (tid >= 2 * kt) + (tid >= 3 * kt), tcol = tid - trow * kt;
+            int trow = 0;
+            for (int rr = 1; rr < R; rr++) trow += tid >= rr * kt;      // (wave-uniform trip count <= DET_MAX_R - 1)
+            const int tcol = tid - trow * kt;
             const int tr = tr0 + trow;
             if (tid < R * kt && tr < lv.nth && xg0 + tcol * tw < W)
                 tile_out[(size_t)b * g.T + lv.tile_off + tr * lv.ntw + grp * kt + tcol] =
@@ -712,7 +716,7 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     // one ds_max_u32 per positive on a per-TILE key (score << 18 | 127 - column priority << 11 | 2047 - row rank) yields the
     // tile winner directly; otherwise the key is per column and phase 4 replays the tree.
     const int SW = L.score_stride;            // (element stride of the plane: score_w, rounded up to even in the compact form)
-    const int n_ty = lv.n_ty, recip_nty = lv.recip_nty, recip_tw = lv.recip_tw;
+    const int n_ty = lv.n_ty, recip_nty = lv.recip_nty, recip_tw = lv.recip_tw, recip_th = lv.recip_th;
     int kt_nms = lv.k_tiles;
     asm volatile("" : "+s"(kt_nms));          // opaque: otherwise the compiler re-loads it from the kernel arguments inside the loop below (a scalar memory round trip per iteration)
     const bool ranked = lv.tree_rank_ok != 0;
@@ -743,9 +747,9 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
                                s >= q[SW - 1] && s >= q[SW] && s >= q[SW + 1];      // (full-plane form: all nine reads at once + one maximum + one branch measured 0.9 % slower, rounds 3 and 4)
             if (!valid) return;
         }
-        int dy = ry - 1, trow = 0;                                       // tile row inside the band and row inside that tile (R <= 4)
+        int dy = ry - 1, trow = 0;                                       // tile row inside the band and row inside that tile
         if (R > 1) {
-            trow = (dy >= th1) + (dy >= 2 * th1) + (dy >= 3 * th1);
+            trow = (int)(__umul24(dy, recip_th) >> 16);                   // dy / th1, exact for dy < 256 (th1 <= 128: dy * (recip * th1 - 65536) < 65536)
             dy -= __umul24(trow, th1);
         }
         const int kk = (int)(__umul24(dy, recip_nty) >> 16), ty = dy - (int)__umul24(kk, n_ty);      // dy / n_ty, exact for dy < 255 (n_ty <= 8; dy * recip < 2^24)
@@ -791,7 +795,9 @@ __device__ __forceinline__ void detect_workgroup(const Geometry &g, const ImageS
     if (ranked) {
         // ---- phase 4 (arg-max form): one thread per tile decodes the winner ----
         const int kt = lv.k_tiles;
-        const int trow = (tid >= kt) + (tid >= 2 * kt) + (tid >= 3 * kt), tcol = tid - trow * kt;      // R <= 4 tile rows of kt tiles
+        int trow = 0;
+        for (int rr = 1; rr < R; rr++) trow += tid >= rr * kt;      // R <= DET_MAX_R tile rows of kt tiles
+        const int tcol = tid - trow * kt;
         const int tr = tr0 + trow;                        // tile row in the level
         if (tid < R * kt && tr < lv.nth && xg0 + tcol * tw < W) {
             const unsigned key = s_colkey[tid];

@@ -68,7 +68,7 @@ def test_compact_detect_layout(orb, name, monkeypatch):
         assert lv["pool"] >= max(256, -(-region // 10)), (i, lv, region)
         assert p["spill_chunk_entries"] >= region
         assert lv["score_stride"] % 2 == 0 and lv["score_stride"] >= lv["k_tiles"] * tw + 2
-        assert 1 <= lv["det_R"] <= 4 and lv["det_R"] * th + 2 <= 255 and lv["det_R"] * lv["k_tiles"] <= 128
+        assert 1 <= lv["det_R"] <= 8 and lv["det_R"] * th + 2 <= 255 and lv["det_R"] * lv["k_tiles"] <= 128
         blocks += -(-lv["tile_rows"] // lv["det_R"]) * (-(-ntw // lv["k_tiles"]))
     assert blocks == p["detect_blocks"]
 
