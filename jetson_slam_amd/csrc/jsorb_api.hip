@@ -22,6 +22,11 @@
 #include "../../include/jsorb.h"
 #include "jsorb_launch.h"
 
+// pyramid megapixels per lane and launch below which every lane of a batch runs the fused k_blur_compact launch (run_pipeline)
+#ifndef JSORB_FUSE_ALL_BELOW_MPX
+#define JSORB_FUSE_ALL_BELOW_MPX 24.0
+#endif
+
 #define JSORB_MAX_LANES 8
 
 using namespace jsorb;
@@ -687,8 +692,17 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         // (k_blur_compact, k_blur.hip; k_compact as a launch of its own is a bubble in its lane): C2 +1.3 %, C5 +1.7 %, C3 +-0 against one order for all
         // lanes.  With large tiles (few keypoints, k_detect most of the step) the same order costs 1-2.5 %: those handles keep the plain order.
         // Not while per-kernel timing is on (stages are timed one by one then).
+        // SMALL launches and ODD lane counts (end of round 6): what the alternating order gains grows with the size of a lane's launches, what the fused
+        // launch saves - one launch and its dependency gap per extract - does not, and with three lanes the alternation is lopsided.  Below 24 megapixels of
+        // pyramid per lane and launch (16 KITTI-shaped images: a 64-pair step), or with an odd number of lanes (64 EuRoC-shaped images: 24 + 24 + 16), every
+        // lane runs the plain order with the fused launch: +3 % in both cases; +-0.6 % between 24 and 36 MPx, -1 ... -4.5 % above (twelve geometry / batch
+        // combinations, tools/micro/r6_lane_order.sh, log sections 33-35).
         // JSORB_LANE_ORDER (experiments build): 0 - every lane plain order with the fused launch, 1 - alternating, 2 - plain order, nothing fused.
-        const int lane_order = experiment_env("JSORB_LANE_ORDER") ? atoi(experiment_env("JSORB_LANE_ORDER")) : (g.lv[0].th <= 40 ? 1 : 2);
+        double lane_mpx = 0;
+        for (int l = 0; l < g.L; l++) lane_mpx += (double)g.lv[l].W * g.lv[l].H;
+        lane_mpx *= (double)n / K * 1e-6;
+        const int lane_order = experiment_env("JSORB_LANE_ORDER") ? atoi(experiment_env("JSORB_LANE_ORDER"))
+                                                                  : (g.lv[0].th <= 40 ? ((K & 1) || lane_mpx < JSORB_FUSE_ALL_BELOW_MPX ? 0 : 1) : 2);
         const bool blur_first = !fused && K > 1 && (j & 1) && lane_order == 1;
         const bool fuse_bc = !fused && !direct && K > 1 && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
         if (blur_first) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));

@@ -84,6 +84,10 @@ __global__ __launch_bounds__(NT) void k_compact_flat(Geometry g, const unsigned 
 #ifndef CMP_NT_BATCH
 #define CMP_NT_BATCH 256
 #endif
+// batches of images with up to this many tiles run the re-reading form with small workgroups as well
+#ifndef CMP_MID_T
+#define CMP_MID_T 8192
+#endif
 
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s, int *counts_host)
@@ -98,6 +102,8 @@ void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsig
     else if (g.T <= 4 * 1024)
         hipLaunchKernelGGL((k_compact_flat<4 * 1024 / NB, NB>), dim3(n_images), dim3(NB), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
     // (4096 < T <= 8192 - the KITTI-shaped images - in the register form with 512 threads: measured, no difference)
+    else if (g.T <= CMP_MID_T && !g.latency)
+        hipLaunchKernelGGL((k_compact_flat<0, NB>), dim3(n_images), dim3(NB), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
     else if (g.T <= CMP_MAX_CHUNKS * 1024)
         hipLaunchKernelGGL((k_compact_flat<0, 1024>), dim3(n_images), dim3(1024), epi, s, g, tile_out, kp, counts, row_tab, counts_host);
     else
