@@ -702,7 +702,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         for (int l = 0; l < g.L; l++) lane_mpx += (double)g.lv[l].W * g.lv[l].H;
         lane_mpx *= (double)n / K * 1e-6;
         const int lane_order = experiment_env("JSORB_LANE_ORDER") ? atoi(experiment_env("JSORB_LANE_ORDER"))
-                                                                  : (g.lv[0].th <= 40 ? ((K & 1) || lane_mpx < JSORB_FUSE_ALL_BELOW_MPX ? 0 : 1) : 2);
+                                                                  : ((K & 1) || lane_mpx < JSORB_FUSE_ALL_BELOW_MPX ? 0 : (g.lv[0].th <= 40 ? 1 : 2));      // (tall tiles as well: C3 / tile 46 +1.1 %, C2 / tile 58 with 64 pairs +1.7 %)
         const bool blur_first = !fused && K > 1 && (j & 1) && lane_order == 1;
         const bool fuse_bc = !fused && !direct && K > 1 && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
         if (blur_first) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));

@@ -7,7 +7,7 @@ fmt='import json,sys; d=json.loads(sys.stdin.readline()); k=d["roofline"]["kerne
 X=$PWD/jetson_slam_amd/csrc/_build/variants/experiments/libjsorb.so
 for cfg in "$@"; do
 for i in $(seq $N); do
-  for o in 1 0; do
+  for o in ${ORDERS:-1 0 2}; do
     JSORB_LIBRARY=$X JSORB_LANE_ORDER=$o python bench.py --no-cpu-baseline --no-extras --min-time 1.0 $cfg 2>/dev/null | tail -1 | python -c "$fmt" "order $o ${cfg#--config }"
   done
 done
