@@ -23,6 +23,9 @@
 #include "jsorb_launch.h"
 
 // pyramid megapixels per lane and launch below which every lane of a batch runs the fused k_blur_compact launch (run_pipeline)
+#ifndef JSORB_FUSE_K1
+#define JSORB_FUSE_K1 0
+#endif
 #ifndef JSORB_FUSE_ALL_BELOW_MPX
 #define JSORB_FUSE_ALL_BELOW_MPX 24.0
 #endif
@@ -704,7 +707,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         const int lane_order = experiment_env("JSORB_LANE_ORDER") ? atoi(experiment_env("JSORB_LANE_ORDER"))
                                                                   : ((K & 1) || lane_mpx < JSORB_FUSE_ALL_BELOW_MPX ? 0 : (g.lv[0].th <= 40 ? 1 : 2));      // (tall tiles as well: C3 / tile 46 +1.1 %, C2 / tile 58 with 64 pairs +1.7 %)
         const bool blur_first = !fused && K > 1 && (j & 1) && lane_order == 1;
-        const bool fuse_bc = !fused && !direct && K > 1 && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
+        const bool fuse_bc = !fused && !direct && (K > 1 || JSORB_FUSE_K1) && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
         if (blur_first) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
         else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st, e->det_spill, e->det_spill_flags));
