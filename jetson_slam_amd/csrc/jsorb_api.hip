@@ -23,9 +23,6 @@
 #include "jsorb_launch.h"
 
 // pyramid megapixels per lane and launch below which every lane of a batch runs the fused k_blur_compact launch (run_pipeline)
-#ifndef JSORB_FUSE_K1
-#define JSORB_FUSE_K1 0
-#endif
 #ifndef JSORB_FUSE_ALL_BELOW_MPX
 #define JSORB_FUSE_ALL_BELOW_MPX 24.0
 #endif
@@ -700,6 +697,8 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         // pyramid per lane and launch (16 KITTI-shaped images: a 64-pair step), or with an odd number of lanes (64 EuRoC-shaped images: 24 + 24 + 16), every
         // lane runs the plain order with the fused launch: +3 % in both cases; +-0.6 % between 24 and 36 MPx, -1 ... -4.5 % above (twelve geometry / batch
         // combinations, tools/micro/r6_lane_order.sh, log sections 33-35).
+        // A batch too small to be split (one lane) takes the fused launch as well when its compaction workgroup is short (<= CMP_MID_T tiles: +8 ... 10 % at 8 / 16
+        // EuRoC-shaped and 12 KITTI-shaped pairs; the 21 053 tiles of the KAIST shape outlast so small a k_blur launch: -13 %, those keep k_compact's own launch).
         // JSORB_LANE_ORDER (experiments build): 0 - every lane plain order with the fused launch, 1 - alternating, 2 - plain order, nothing fused.
         double lane_mpx = 0;
         for (int l = 0; l < g.L; l++) lane_mpx += (double)g.lv[l].W * g.lv[l].H;
@@ -707,7 +706,7 @@ int run_pipeline(jsorb_extractor *e, int n, const hipEvent_t *input_ready = null
         const int lane_order = experiment_env("JSORB_LANE_ORDER") ? atoi(experiment_env("JSORB_LANE_ORDER"))
                                                                   : ((K & 1) || lane_mpx < JSORB_FUSE_ALL_BELOW_MPX ? 0 : (g.lv[0].th <= 40 ? 1 : 2));      // (tall tiles as well: C3 / tile 46 +1.1 %, C2 / tile 58 with 64 pairs +1.7 %)
         const bool blur_first = !fused && K > 1 && (j & 1) && lane_order == 1;
-        const bool fuse_bc = !fused && !direct && (K > 1 || JSORB_FUSE_K1) && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
+        const bool fuse_bc = !fused && !direct && (K > 1 || g.T <= CMP_MID_T) && !blur_first && !e->timing && lane_order != 2 && blur_compact_fusable(g);
         if (blur_first) JSORB_STAGE(JSORB_K_BLUR, launch_blur(g, src, slab, blur, e->lut_bits, m, st));
         if (fused) JSORB_STAGE(JSORB_K_DETECT, launch_detect_blur(g, src, slab, e->mask, e->lut_bits, tile_out, blur, e->detect_lds, st));
         else JSORB_STAGE(JSORB_K_DETECT, launch_detect(g, src, slab, e->mask, e->lut_bits, tile_out, m, e->detect_lds, st, e->det_spill, e->det_spill_flags));

@@ -29,6 +29,11 @@ void launch_upload_level0(const uint8_t *host_pinned, uint8_t *dst, size_t bytes
 void launch_copy_level0(const uint8_t *src, size_t image_stride, int step, uint8_t *slab, size_t slab_bytes, int pitch, int W, int H, int n_images, hipStream_t s);
 void launch_pyramid(const Geometry &g, const ImageSrc &src, uint8_t *slab, const uint32_t *ctab, int n_images, size_t lds_bytes, hipStream_t s);
 int detect_ring_bit_of_pixel(int k);       // bit of ring pixel k in the index of the arc LUT as k_detect forms it (the host stores the LUT in that order)
+// images with up to this many tiles: k_compact as a launch of its own runs its re-reading form with 256-thread workgroups on batch handles (k_compact.hip), and a
+// batch of one lane takes the fused k_blur_compact launch (jsorb_api.hip: run_pipeline)
+#ifndef CMP_MID_T
+#define CMP_MID_T 8192
+#endif
 void fill_detect_layout(Geometry &g);      // tile rows per workgroup (det_R), workgroup table offsets and per-level LDS layout of k_detect (host side, once per handle)
 void launch_detect(const Geometry &g, const ImageSrc &src, const uint8_t *slab, const uint8_t *mask_slab,
                    const uint32_t *lut_bits, unsigned long long *tile_out, int n_images, size_t lds_bytes, hipStream_t s,

@@ -84,10 +84,6 @@ __global__ __launch_bounds__(NT) void k_compact_flat(Geometry g, const unsigned 
 #ifndef CMP_NT_BATCH
 #define CMP_NT_BATCH 256
 #endif
-// batches of images with up to this many tiles run the re-reading form with small workgroups as well
-#ifndef CMP_MID_T
-#define CMP_MID_T 8192
-#endif
 
 void launch_compact(const Geometry &g, const unsigned long long *tile_out, unsigned long long *kp, int *counts,
                     int *row_tab, int n_images, hipStream_t s, int *counts_host)
