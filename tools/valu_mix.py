@@ -28,12 +28,12 @@ FULL_RATE = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32",
              "v_accvgpr_read_b32", "v_mov_b64"}
 SLOW8 = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32", "v_div_scale_f32", "v_div_fmas_f32",
          "v_div_fixup_f32"}
-KERNELS = {"k_pyramid.hip": ["k_pyramid"], "k_detect.hip": ["k_detect"], "k_blur.hip": ["k_blur"], "k_describe.hip": ["k_describe"],
+KERNELS = {"k_pyramid.hip": ["k_pyramid"], "k_detect.hip": ["k_detect"], "k_blur.hip": ["k_blur", "k_blur_compact"], "k_describe.hip": ["k_describe"],
            "k_stereo.hip": ["k_stereo", "k_median"], "k_compact.hip": ["k_compact_flat"]}
 
 
 # the instantiation bench.py's default configuration launches (no mask, compass LUT, 6-bit early rejects, compact form)
-PREFERRED = {"k_detect": "8k_detectILb0ELb1ELb1ELb1E"}
+PREFERRED = {"k_detect": "8k_detectILb0ELb1ELb1ELb1E", "k_blur_compact": "14k_blur_compactILi16E"}      # (k_blur_compact<16>: images with <= 4096 tiles; a one-lane batch - the profile runs - takes the fused launch)
 
 
 def issue_clocks(line):
